@@ -1,0 +1,222 @@
+/*
+ * tbe_hip.h — C ABI of the MI355X (gfx950) sharded-embedding hot path.
+ *
+ * This is the drop-in boundary.  The reference (samiwilf/torchrec-oldfork) has no C
+ * ABI of its own for this path: it calls the un-vendored `fbgemm_gpu` Python module /
+ * `torch.ops.fbgemm.*` dispatcher ops (third_party/fbgemm is an empty submodule,
+ * .gitmodules:1-4).  Every entry point below replaces one of those call sites; the
+ * reference file:line it serves is cited on each declaration.  The Python host side
+ * (`torchrec-oldfork_amd/fbgemm_gpu/`) binds this header with ctypes and re-exposes
+ * the reference's names (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *  - Every pointer is a DEVICE-visible address (hipMalloc, or pinned-host memory
+ *    mapped into the GPU for EmbeddingLocation.MANAGED/HOST tables) unless marked
+ *    `host`.  No torch types; no allocation; no host synchronisation: every call
+ *    only enqueues kernels on `stream` (a hipStream_t passed as void*), so callers
+ *    may capture them into a hipGraph.
+ *  - Return value: 0 on success, negative TBE_ERR_* otherwise;
+ *    `tbe_last_error()` gives a thread-local message.
+ *  - "feature metadata" arrays (feat_*) have one entry per FEATURE (not per table):
+ *    feature f of the KeyedJaggedTensor looks up table feature_table_map[f]; the
+ *    host resolves that indirection once at module construction.
+ *  - Jagged layout is the reference's (torchrec/sparse/jagged_tensor.py:614-1081):
+ *    `offsets[f*B + b] .. offsets[f*B + b + 1]` delimits bag (feature f, sample b)
+ *    inside `indices`; offsets has F*B+1 entries.
+ */
+#ifndef TBE_HIP_H_
+#define TBE_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TBE_OK 0
+#define TBE_ERR_INVALID_ARGUMENT (-1)
+#define TBE_ERR_LAUNCH (-2)
+#define TBE_ERR_WORKSPACE (-3)
+#define TBE_ERR_UNSUPPORTED (-4)
+
+/* fbgemm_gpu.split_table_batched_embeddings_ops.PoolingMode
+ * (torchrec/distributed/batched_embedding_kernel.py:18-25, embedding_configs.py:59-73) */
+#define TBE_POOL_SUM 0
+#define TBE_POOL_MEAN 1
+#define TBE_POOL_NONE 2
+
+/* fbgemm_gpu.split_embedding_configs.EmbOptimType as used through fused_params
+ * (torchrec/distributed/tests/test_fused_optim.py:52-58, examples/bert4rec/bert4rec_main.py:488-491).
+ * TBE_OPT_DENSE_GRAD is the DenseTableBatchedEmbeddingBagsCodegen backward
+ * (batched_embedding_kernel.py:677-704): the coalesced row gradient is written to a
+ * dense gradient table instead of being applied. */
+#define TBE_OPT_EXACT_SGD 0
+#define TBE_OPT_EXACT_ROWWISE_ADAGRAD 1
+#define TBE_OPT_ADAM 2
+#define TBE_OPT_EXACT_ADAGRAD 3
+#define TBE_OPT_DENSE_GRAD 100
+
+/* Hyper-parameters of the fused optimizer, passed by value. */
+typedef struct tbe_optimizer_args {
+  int32_t optimizer;     /* TBE_OPT_* */
+  float learning_rate;   /* set_learning_rate(), batched_embedding_kernel.py:250-257 */
+  float eps;
+  float weight_decay;
+  float beta1;
+  float beta2;
+  int64_t iteration;     /* 1-based step count, used by ADAM bias correction */
+} tbe_optimizer_args;
+
+const char* tbe_last_error(void);
+int32_t tbe_abi_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * TBE forward (pooled): replaces SplitTableBatchedEmbeddingBagsCodegen.__call__ /
+ * DenseTableBatchedEmbeddingBagsCodegen.__call__ as called at
+ * torchrec/distributed/batched_embedding_kernel.py:546-554.
+ *
+ *   out[b, feat_D_offset[f] + d] = sum_{i in bag(f,b)} w_i * W_f[indices[i], d]
+ *   (w_i = per_sample_weights[i] or 1; MEAN divides by the bag length)
+ *
+ * feat_weights   [F] device array of table base addresses (const float*), one per feature
+ * feat_D         [F] embedding dim of the feature's table
+ * feat_D_offset  [F+1] column offset of the feature in the pooled output (prefix sum of feat_D)
+ * feat_rows      [F] number of rows of the feature's table (bounds check)
+ * indices [N] int64, offsets [F*B+1] int64, per_sample_weights [N] float or NULL
+ * out [B, out_row_stride] float, out_row_stride >= total_D (in elements)
+ * bounds_errors  optional device int32 counter: incremented for every index outside
+ *                [0, rows); such an index contributes a zero row (never dereferenced).
+ * ---------------------------------------------------------------------------------- */
+int tbe_forward_pooled_f32(const uint64_t* feat_weights, const int32_t* feat_D,
+                           const int32_t* feat_D_offset, const int64_t* feat_rows, int32_t F,
+                           int32_t B, int32_t total_D, int32_t max_D, const int64_t* indices,
+                           int64_t N, const int64_t* offsets, const float* per_sample_weights,
+                           int32_t pooling_mode, float* out, int64_t out_row_stride,
+                           int32_t* bounds_errors, void* stream);
+
+/* TBE forward, PoolingMode.NONE (sequence / unpooled): out[i, :] = W_f(i)[indices[i], :]
+ * with f(i) the feature whose offsets range contains i.  All features must share one
+ * dim D.  Replaces batched_embedding_kernel.py:332-335 (BatchedFusedEmbedding.forward). */
+int tbe_forward_nobag_f32(const uint64_t* feat_weights, const int64_t* feat_rows, int32_t F,
+                          int32_t B, int32_t D, const int64_t* indices, int64_t N,
+                          const int64_t* offsets, float* out, int32_t* bounds_errors,
+                          void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * TBE backward + fused "exact" optimizer: the autograd backward of the call above
+ * plus the in-backward optimizer fbgemm fuses into it (wired by
+ * batched_embedding_kernel.py:604-665 BatchedFusedEmbeddingBag and :53-257
+ * EmbeddingFusedOptimizer).  "Exact" = all contributions of one batch to the same
+ * table row are summed first (deterministic, position order), then ONE update is
+ * applied to the row.
+ *
+ * feat_row_base [F]  global row number of row 0 of the feature's table (features that
+ *                    share a table share the base); key_bits = bits needed to hold the
+ *                    largest global row number.
+ * feat_state0/1 [F]  base addresses of optimizer state of the feature's table
+ *                    (rowwise Adagrad: float[rows] momentum1; ADAM: float[rows*D] m, v;
+ *                    DENSE_GRAD: state0 = float[rows*D] dense gradient table). May be NULL
+ *                    for SGD.
+ * grad_out [B, grad_row_stride] float (pooled) or [N, D] (pooling_mode NONE).
+ * workspace: at least tbe_backward_workspace_bytes(N, F, B, max_D, key_bits) bytes.
+ * ---------------------------------------------------------------------------------- */
+size_t tbe_backward_workspace_bytes(int64_t N, int32_t F, int32_t B, int32_t max_D,
+                                    int32_t key_bits);
+
+int tbe_backward_fused_f32(const uint64_t* feat_weights, const int32_t* feat_D,
+                           const int32_t* feat_D_offset, const int64_t* feat_rows,
+                           const int64_t* feat_row_base, const uint64_t* feat_state0,
+                           const uint64_t* feat_state1, int32_t F, int32_t B, int32_t total_D,
+                           int32_t max_D, int32_t key_bits, const int64_t* indices, int64_t N,
+                           const int64_t* offsets, const float* per_sample_weights,
+                           int32_t pooling_mode, const float* grad_out,
+                           int64_t grad_row_stride, tbe_optimizer_args opt, void* workspace,
+                           size_t workspace_bytes, int32_t* bounds_errors, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * torch.ops.fbgemm.asynchronous_complete_cumsum (torchrec/sparse/jagged_tensor.py:35-36):
+ * out[0] = 0, out[i+1] = sum(in[0..i]); out has n+1 entries.  elem_size 4 (int32) or
+ * 8 (int64).  workspace >= tbe_cumsum_workspace_bytes(n).
+ * `mode`: 0 = complete (n+1 outputs), 1 = inclusive (n outputs), 2 = exclusive (n outputs)
+ * ---------------------------------------------------------------------------------- */
+size_t tbe_cumsum_workspace_bytes(int64_t n);
+int tbe_cumsum(const void* in, void* out, int64_t n, int32_t elem_size, int32_t mode,
+               void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * torch.ops.fbgemm.permute_2D_sparse_data (torchrec/sparse/jagged_tensor.py:946-952,
+ * torchrec/distributed/dist_data.py:257-263, comm_ops.py:633-639,691-697).
+ * Two steps so that the host can size the outputs without a sync when it already
+ * knows permuted_lengths_sum:
+ *  1. tbe_permute_2d_lengths: out_lengths[t', b] = lengths[permute[t'], b]
+ *     and in_offsets / out_offsets = exclusive complete cumsums (T*B+1 / T'*B+1 entries,
+ *     int64) written to caller buffers.
+ *  2. tbe_permute_2d_data: for each (t', b) copy the segment of `values` (and `weights`).
+ * lengths elem size 4 or 8; values/weights element size 1, 2, 4 or 8 bytes (opaque copy).
+ * ---------------------------------------------------------------------------------- */
+size_t tbe_permute_2d_workspace_bytes(int32_t T_in, int32_t T_out, int32_t B);
+int tbe_permute_2d_lengths(const int32_t* permute, int32_t T_in, int32_t T_out, int32_t B,
+                           const void* lengths, int32_t len_elem_size, void* out_lengths,
+                           int64_t* in_offsets, int64_t* out_offsets, void* workspace,
+                           size_t workspace_bytes, void* stream);
+int tbe_permute_2d_data(const int32_t* permute, int32_t T_out, int32_t B,
+                        const int64_t* in_offsets, const int64_t* out_offsets,
+                        const void* values, void* out_values, int32_t val_elem_size,
+                        const void* weights, void* out_weights, int32_t w_elem_size,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * torch.ops.fbgemm.block_bucketize_sparse_features
+ * (torchrec/distributed/embedding_sharding.py:121-184; python reference of the result:
+ * torchrec/distributed/tests/test_utils.py:83-236).
+ *   bucket = idx / block_sizes[f];  new idx = idx % block_sizes[f]
+ *   new_lengths[bucket*F*B + f*B + b] counts; new_indices ordered (bucket, f, b), stable.
+ *   indices whose bucket >= my_size are dropped (as the python reference does).
+ * lengths [F*B] (elem 4|8), indices [N] (elem 4|8), block_sizes [F] (same elem size as indices)
+ * weights [N] float or NULL; out pos [N] (same elem as indices) if bucketize_pos;
+ * unbucketize_permute [N] (same elem as indices) if sequence.
+ * workspace >= tbe_bucketize_workspace_bytes(F*B, my_size).
+ * new_offsets_out: optional int64 [my_size*F*B + 1] complete cumsum of new_lengths
+ *   (lets the host read per-bucket totals without recomputing).
+ * ---------------------------------------------------------------------------------- */
+size_t tbe_bucketize_workspace_bytes(int64_t lengths_size, int32_t my_size);
+int tbe_block_bucketize(const void* lengths, int32_t len_elem_size, int64_t lengths_size,
+                        const void* indices, int32_t idx_elem_size, int64_t N,
+                        const void* block_sizes, int32_t F, int32_t my_size,
+                        const float* weights, int32_t bucketize_pos, int32_t sequence,
+                        void* new_lengths, void* new_indices, float* new_weights,
+                        void* new_pos, void* unbucketize_permute, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Pooled-embedding all-to-all layout ops.  The reference does these with
+ * torch split + cat copies (torchrec/distributed/comm_ops.py:555-561 forward,
+ * :418-428 `_recat_pooled_embedding_grad_out` backward, flagged slow by its own TODO :417).
+ *   tbe_a2a_pooled_unpack : recv[src][B_local][D_src] slabs -> out[B_local, sum D_src]
+ *   tbe_a2a_pooled_pack   : grad[B_local, sum D_src]       -> send[src][B_local][D_src]
+ * dim_sum_per_rank [W] int32 device array; dims_multiple_of_4 != 0 asserts every entry is a
+ * multiple of 4 (enables 16-B accesses); scale multiplies every element (the 1/W gradient
+ * division of comm_ops.py:527-528 can be fused here).
+ * ---------------------------------------------------------------------------------- */
+int tbe_a2a_pooled_unpack(const float* recv, float* out, const int32_t* dim_sum_per_rank,
+                          int32_t W, int32_t B_local, int32_t D_total,
+                          int32_t dims_multiple_of_4, float scale, void* stream);
+int tbe_a2a_pooled_pack(const float* grad, float* send, const int32_t* dim_sum_per_rank,
+                        int32_t W, int32_t B_local, int32_t D_total,
+                        int32_t dims_multiple_of_4, float scale, void* stream);
+
+/* torch.ops.fbgemm.jagged_2d_to_dense (examples/bert4rec/models/bert4rec.py:394-400):
+ * values [N, D] + offsets [B+1] -> dense [B, max_L, D], zero padded / truncated. */
+int tbe_jagged_2d_to_dense_f32(const float* values, const int64_t* offsets, int32_t B,
+                               int32_t D, int32_t max_L, float* dense, void* stream);
+
+/* torch.ops.fbgemm.offsets_range (torchrec/modules/feature_processor.py:65):
+ * out[i] = i - offsets[bag(i)] for i in [0, range_size). offsets has n entries (no total). */
+int tbe_offsets_range(const int64_t* offsets, int64_t n, int64_t range_size, int64_t* out,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TBE_HIP_H_ */

@@ -1,0 +1,65 @@
+"""CPU: the C-ABI library loads and exports every symbol include/tbe_hip.h declares
+(no compute calls without a GPU), and the product refuses CPU tensors loudly."""
+import os
+import re
+
+import pytest
+import torch
+
+import _paths
+from fbgemm_gpu import _lib
+
+
+def declared_symbols():
+    hdr = open(os.path.join(_paths.ROOT, "include", "tbe_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(tbe_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = declared_symbols()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/tbe_hip.h but not exported"
+    assert set(names) == set(_lib.SIGNATURES), "ctypes SIGNATURES out of sync with the header"
+    assert lib.tbe_abi_version() == 1
+
+
+def test_argument_validation_happens_before_any_launch():
+    lib = _lib.load()
+    rc = lib.tbe_cumsum(None, None, -1, 4, 0, None, 0, None)
+    assert rc == -1 and b"n < 0" in lib.tbe_last_error()
+    rc = lib.tbe_forward_pooled_f32(None, None, None, None, 0, 1, 0, 0, None, 0, None, None, 0, None, 0, None, None)
+    assert rc == -1
+
+
+def test_cpu_tensors_are_refused_not_silently_computed():
+    from fbgemm_gpu import _ops
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _ops.asynchronous_complete_cumsum(torch.tensor([1, 2, 3], dtype=torch.int32))
+    from fbgemm_gpu.split_table_batched_embeddings_ops import (
+        ComputeDevice, DenseTableBatchedEmbeddingBagsCodegen, EmbeddingLocation,
+        SplitTableBatchedEmbeddingBagsCodegen)
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        SplitTableBatchedEmbeddingBagsCodegen([(10, 4, EmbeddingLocation.HOST, ComputeDevice.CPU)])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        DenseTableBatchedEmbeddingBagsCodegen([(10, 4)], use_cpu=True)
+
+
+def test_enum_surface_used_by_reference():
+    # names imported at torchrec/distributed/batched_embedding_kernel.py:17-25,
+    # embedding_types.py:14, modules/embedding_configs.py:14-15
+    from fbgemm_gpu.split_embedding_configs import EmbOptimType, SparseType
+    from fbgemm_gpu.split_table_batched_embeddings_ops import (  # noqa: F401
+        ComputeDevice, DenseTableBatchedEmbeddingBagsCodegen, EmbeddingLocation,
+        IntNBitTableBatchedEmbeddingBagsCodegen, PoolingMode, SplitTableBatchedEmbeddingBagsCodegen,
+        rounded_row_size_in_bytes)
+    from fbgemm_gpu.permute_pooled_embedding_modules import PermutePooledEmbeddings  # noqa: F401
+
+    assert [e.name for e in EmbeddingLocation] == ["DEVICE", "MANAGED", "MANAGED_CACHING", "HOST"]
+    assert {e.name for e in PoolingMode} == {"SUM", "MEAN", "NONE"}
+    assert {"FP32", "FP16", "INT8", "INT4", "INT2"} <= {e.name for e in SparseType}
+    assert {"EXACT_SGD", "EXACT_ROWWISE_ADAGRAD", "ADAM"} <= {e.name for e in EmbOptimType}

@@ -1,0 +1,73 @@
+// Shared helpers for the gfx950 TBE kernels.  gfx950 only: wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/tbe_hip.h"
+
+namespace tbe {
+
+constexpr int kWave = 64;
+
+void set_error(const char* fmt, ...);
+
+#define TBE_REQUIRE(cond, ...)            \
+  do {                                    \
+    if (!(cond)) {                        \
+      ::tbe::set_error(__VA_ARGS__);      \
+      return TBE_ERR_INVALID_ARGUMENT;    \
+    }                                     \
+  } while (0)
+
+#define TBE_CHECK_LAUNCH(what)                                              \
+  do {                                                                      \
+    hipError_t e__ = hipGetLastError();                                     \
+    if (e__ != hipSuccess) {                                                \
+      ::tbe::set_error("%s: launch failed: %s", what, hipGetErrorString(e__)); \
+      return TBE_ERR_LAUNCH;                                                \
+    }                                                                       \
+  } while (0)
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Carves 256-byte aligned sub-buffers out of a caller workspace.
+struct Carver {
+  char* base;
+  size_t used = 0;
+  explicit Carver(void* p) : base(static_cast<char*>(p)) {}
+  template <typename T>
+  T* take(size_t count) {
+    used = align_up(used, 256);
+    T* r = reinterpret_cast<T*>(base ? base + used : nullptr);
+    used += count * sizeof(T);
+    return r;
+  }
+  void* take_bytes(size_t bytes) {
+    used = align_up(used, 256);
+    void* r = base ? base + used : nullptr;
+    used += bytes;
+    return r;
+  }
+  size_t total() const { return align_up(used, 256); }
+};
+
+// Broadcast lane `src` (0..63) of a 64-bit value.
+__device__ __forceinline__ int64_t shfl64(int64_t v, int src) {
+  int lo = __shfl(static_cast<int>(v & 0xffffffffll), src, kWave);
+  int hi = __shfl(static_cast<int>(v >> 32), src, kWave);
+  return (static_cast<int64_t>(hi) << 32) | static_cast<uint32_t>(lo);
+}
+__device__ __forceinline__ uint64_t shflu64(uint64_t v, int src) {
+  return static_cast<uint64_t>(shfl64(static_cast<int64_t>(v), src));
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) {
+  return *reinterpret_cast<const float4*>(p);
+}
+__device__ __forceinline__ void st4(float* p, float4 v) {
+  *reinterpret_cast<float4*>(p) = v;
+}
+
+}  // namespace tbe

@@ -1,0 +1,664 @@
+// TBE backward + fused "exact" optimizer for gfx950.
+//
+// Reference wiring: torchrec/distributed/batched_embedding_kernel.py:604-665
+// (BatchedFusedEmbeddingBag) and :53-257 (EmbeddingFusedOptimizer); the arithmetic itself
+// lives in fbgemm_gpu, which is absent from the reference tree.  "Exact" optimizers sum
+// every contribution a batch makes to one table row BEFORE applying a single update
+// (pinned for EXACT_SGD by torchrec/distributed/test_utils/test_model_parallel_base.py:257-283,
+// which compares against nn.EmbeddingBag + torch.optim.SGD).
+//
+// Pipeline (all on `stream`, no host sync, no atomics on floats => bitwise reproducible):
+//  1. linearize : key[p] = feat_row_base[f] + indices[p]  (invalid index -> sentinel),
+//                 payload[p] = (bag << 32) | p             (thread per bag, coalesced at L = 1)
+//  2. sort      : stable LSD radix sort of (key, payload) on the low key_bits bits
+//                 (rocPRIM device radix sort)
+//  3. update    : the sorted contributions are cut into fixed chunks of C; one G-lane group
+//                 walks a chunk, 4 gradient rows + 4 weight rows in flight, accumulates
+//                 runs of equal keys in registers and applies the optimizer when a run
+//                 ends inside the chunk.  Runs that cross a chunk boundary leave a
+//                 partial row in the workspace.
+//  4. fixup     : the chunk where a crossing run started sums the partials in chunk
+//                 order and applies the update.
+// Fixed chunks keep the work balanced no matter how skewed the ids are (a 3-row table
+// receives B contributions per row).
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include <algorithm>
+
+#include "common.hpp"
+
+namespace tbe {
+
+struct BwdArgs {
+  const uint64_t* feat_weights;
+  const int32_t* feat_D;
+  const int32_t* feat_D_offset;
+  const int64_t* feat_rows;
+  const int64_t* feat_row_base;
+  const uint64_t* feat_state0;
+  const uint64_t* feat_state1;
+  const int64_t* indices;
+  const int64_t* offsets;
+  const float* psw;
+  const float* grad_out;
+  int64_t grad_stride;
+  int64_t N;
+  int32_t F;
+  int32_t B;
+  int32_t pooling_mode;
+  int32_t key_bits;
+  int32_t C;  // contributions per chunk
+  tbe_optimizer_args opt;
+  float bias1;  // ADAM: 1 - beta1^t
+  float bias2;  // ADAM: 1 - beta2^t
+  // workspace
+  void* keys_sorted;
+  const uint64_t* payload_sorted;
+  float* partial_first;  // [nchunks][max_D_pad]
+  float* partial_last;   // [nchunks][max_D_pad]
+  int32_t* origin;       // [nchunks]
+  int32_t max_D_pad;
+  int32_t* bounds_errors;
+};
+
+template <typename KeyT>
+__global__ __launch_bounds__(256) void bwd_linearize_pooled_kernel(
+    const int64_t* __restrict__ indices, const int64_t* __restrict__ offsets,
+    const int64_t* __restrict__ feat_rows, const int64_t* __restrict__ feat_row_base, int F, int B,
+    int key_bits, KeyT* __restrict__ keys, uint64_t* __restrict__ payload,
+    int32_t* bounds_errors) {
+  const int64_t bag = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (bag >= static_cast<int64_t>(F) * B) return;
+  const int f = static_cast<int>(bag / B);
+  const int64_t s = offsets[bag];
+  const int64_t e = offsets[bag + 1];
+  const int64_t rows = feat_rows[f];
+  const int64_t base = feat_row_base[f];
+  const KeyT sentinel = static_cast<KeyT>((key_bits >= 64) ? ~0ull : ((1ull << key_bits) - 1ull));
+  int nbad = 0;
+  for (int64_t p = s; p < e; ++p) {
+    const int64_t idx = indices[p];
+    const bool ok = static_cast<uint64_t>(idx) < static_cast<uint64_t>(rows);
+    if (!ok) ++nbad;
+    keys[p] = ok ? static_cast<KeyT>(base + idx) : sentinel;
+    payload[p] = (static_cast<uint64_t>(bag) << 32) | static_cast<uint32_t>(p);
+  }
+  if (nbad > 0 && bounds_errors != nullptr) atomicAdd(bounds_errors, nbad);
+}
+
+// PoolingMode.NONE: position p belongs to feature f(p); "bag" is encoded as f*B so that the
+// update kernel recovers f with the same division.
+template <typename KeyT>
+__global__ __launch_bounds__(256) void bwd_linearize_nobag_kernel(
+    const int64_t* __restrict__ indices, const int64_t* __restrict__ offsets,
+    const int64_t* __restrict__ feat_rows, const int64_t* __restrict__ feat_row_base, int F, int B,
+    int64_t N, int key_bits, KeyT* __restrict__ keys, uint64_t* __restrict__ payload,
+    int32_t* bounds_errors) {
+  extern __shared__ int64_t fb[];
+  for (int i = threadIdx.x; i <= F; i += blockDim.x) fb[i] = offsets[static_cast<int64_t>(i) * B];
+  __syncthreads();
+  const KeyT sentinel = static_cast<KeyT>((key_bits >= 64) ? ~0ull : ((1ull << key_bits) - 1ull));
+  for (int64_t p = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; p < N;
+       p += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    int lo = 0, hi = F;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (fb[mid] <= p) lo = mid; else hi = mid;
+    }
+    const int f = lo;
+    const int64_t idx = indices[p];
+    const bool ok = static_cast<uint64_t>(idx) < static_cast<uint64_t>(feat_rows[f]);
+    if (!ok && bounds_errors != nullptr) atomicAdd(bounds_errors, 1);
+    keys[p] = ok ? static_cast<KeyT>(feat_row_base[f] + idx) : sentinel;
+    payload[p] = (static_cast<uint64_t>(static_cast<int64_t>(f) * B) << 32) | static_cast<uint32_t>(p);
+  }
+}
+
+__device__ __forceinline__ float4 ldc(const float* row, int d, int D, bool vec) {
+  float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (vec) {
+    x = ld4(row + d);
+  } else {
+    if (d + 0 < D) x.x = row[d + 0];
+    if (d + 1 < D) x.y = row[d + 1];
+    if (d + 2 < D) x.z = row[d + 2];
+    if (d + 3 < D) x.w = row[d + 3];
+  }
+  return x;
+}
+__device__ __forceinline__ void stc(float* row, int d, int D, bool vec, float4 x) {
+  if (vec) {
+    st4(row + d, x);
+  } else {
+    if (d + 0 < D) row[d + 0] = x.x;
+    if (d + 1 < D) row[d + 1] = x.y;
+    if (d + 2 < D) row[d + 2] = x.z;
+    if (d + 3 < D) row[d + 3] = x.w;
+  }
+}
+
+// Sum over the G lanes of a group (G consecutive lanes), fixed butterfly order.
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = G / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o, kWave);
+  return v;
+}
+
+// Applies the optimizer to one table row.  `g` = coalesced gradient columns held by this lane,
+// `w` = current weight columns (pre-loaded).  Group-uniform control flow.
+template <int G, int NV>
+__device__ __forceinline__ void apply_row(const BwdArgs& a, int f, int64_t local_row, int D,
+                                          bool vec, int gl, float* wrow, float4 (&w)[NV],
+                                          float4 (&g)[NV]) {
+  const int optimizer = a.opt.optimizer;
+  const float lr = a.opt.learning_rate;
+  if (optimizer == TBE_OPT_EXACT_SGD) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int d = (v * G + gl) * 4;
+      if (d < D) {
+        float4 r;
+        r.x = fmaf(-lr, g[v].x, w[v].x);
+        r.y = fmaf(-lr, g[v].y, w[v].y);
+        r.z = fmaf(-lr, g[v].z, w[v].z);
+        r.w = fmaf(-lr, g[v].w, w[v].w);
+        stc(wrow, d, D, vec, r);
+      }
+    }
+  } else if (optimizer == TBE_OPT_EXACT_ROWWISE_ADAGRAD) {
+    const float wd = a.opt.weight_decay;
+    float ss = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int d = (v * G + gl) * 4;
+      if (d < D) {
+        if (wd != 0.f) {
+          g[v].x = fmaf(wd, w[v].x, g[v].x);
+          g[v].y = fmaf(wd, w[v].y, g[v].y);
+          g[v].z = fmaf(wd, w[v].z, g[v].z);
+          g[v].w = fmaf(wd, w[v].w, g[v].w);
+        }
+        // columns beyond D are zero in g (never loaded), so the vector form is safe
+        ss = fmaf(g[v].x, g[v].x, ss);
+        ss = fmaf(g[v].y, g[v].y, ss);
+        ss = fmaf(g[v].z, g[v].z, ss);
+        ss = fmaf(g[v].w, g[v].w, ss);
+      }
+    }
+    ss = group_sum<G>(ss);
+    float* m = reinterpret_cast<float*>(a.feat_state0[f]) + local_row;
+    const float m_new = *m + ss / static_cast<float>(D);
+    const float mult = lr / (sqrtf(m_new) + a.opt.eps);
+    if (gl == 0) *m = m_new;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int d = (v * G + gl) * 4;
+      if (d < D) {
+        float4 r;
+        r.x = fmaf(-mult, g[v].x, w[v].x);
+        r.y = fmaf(-mult, g[v].y, w[v].y);
+        r.z = fmaf(-mult, g[v].z, w[v].z);
+        r.w = fmaf(-mult, g[v].w, w[v].w);
+        stc(wrow, d, D, vec, r);
+      }
+    }
+  } else if (optimizer == TBE_OPT_DENSE_GRAD) {
+    float* grow = reinterpret_cast<float*>(a.feat_state0[f]) + local_row * D;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int d = (v * G + gl) * 4;
+      if (d < D) stc(grow, d, D, vec && ((reinterpret_cast<uintptr_t>(grow) & 15) == 0), g[v]);
+    }
+  } else if (optimizer == TBE_OPT_EXACT_ADAGRAD) {
+    float* mrow = reinterpret_cast<float*>(a.feat_state0[f]) + local_row * D;
+    const bool mvec = vec && ((reinterpret_cast<uintptr_t>(mrow) & 15) == 0);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int d = (v * G + gl) * 4;
+      if (d < D) {
+        float4 m = ldc(mrow, d, D, mvec);
+        m.x = fmaf(g[v].x, g[v].x, m.x);
+        m.y = fmaf(g[v].y, g[v].y, m.y);
+        m.z = fmaf(g[v].z, g[v].z, m.z);
+        m.w = fmaf(g[v].w, g[v].w, m.w);
+        stc(mrow, d, D, mvec, m);
+        float4 r;
+        r.x = w[v].x - lr * g[v].x / (sqrtf(m.x) + a.opt.eps);
+        r.y = w[v].y - lr * g[v].y / (sqrtf(m.y) + a.opt.eps);
+        r.z = w[v].z - lr * g[v].z / (sqrtf(m.z) + a.opt.eps);
+        r.w = w[v].w - lr * g[v].w / (sqrtf(m.w) + a.opt.eps);
+        stc(wrow, d, D, vec, r);
+      }
+    }
+  } else if (optimizer == TBE_OPT_ADAM) {
+    float* m1row = reinterpret_cast<float*>(a.feat_state0[f]) + local_row * D;
+    float* m2row = reinterpret_cast<float*>(a.feat_state1[f]) + local_row * D;
+    const bool mvec = vec && ((reinterpret_cast<uintptr_t>(m1row) & 15) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(m2row) & 15) == 0);
+    const float b1 = a.opt.beta1, b2 = a.opt.beta2, eps = a.opt.eps, wd = a.opt.weight_decay;
+#define TBE_ADAM1(c)                                                     \
+  m1.c = fmaf(b1, m1.c, (1.f - b1) * g[v].c);                            \
+  m2.c = fmaf(b2, m2.c, (1.f - b2) * g[v].c * g[v].c);                   \
+  r.c = w[v].c - lr * ((m1.c / a.bias1) / (sqrtf(m2.c / a.bias2) + eps) + wd * w[v].c);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int d = (v * G + gl) * 4;
+      if (d < D) {
+        float4 m1 = ldc(m1row, d, D, mvec);
+        float4 m2 = ldc(m2row, d, D, mvec);
+        float4 r;
+        TBE_ADAM1(x) TBE_ADAM1(y) TBE_ADAM1(z) TBE_ADAM1(w)
+        stc(m1row, d, D, mvec, m1);
+        stc(m2row, d, D, mvec, m2);
+        stc(wrow, d, D, vec, r);
+      }
+    }
+#undef TBE_ADAM1
+  }
+}
+
+template <int NV>
+struct BwdUnroll {
+  static constexpr int U = NV == 1 ? 4 : (NV == 2 ? 2 : 1);
+};
+
+template <typename KeyT, int G, int NV>
+__global__ __launch_bounds__(256) void bwd_update_kernel(BwdArgs a) {
+  constexpr int NG = kWave / G;
+  constexpr int U = BwdUnroll<NV>::U;
+  const int lane = threadIdx.x & 63;
+  const int g = lane / G;
+  const int gl = lane % G;
+  const int gbase = g * G;  // first lane of this group
+  const int64_t nchunks = (a.N + a.C - 1) / a.C;
+  const int64_t chunk = (static_cast<int64_t>(blockIdx.x) * (blockDim.x / kWave) + (threadIdx.x >> 6)) * NG + g;
+  // Whole wave out of range -> exit; a partially filled wave keeps its idle groups alive
+  // (they execute the shuffles with in-range flags false).
+  const int64_t chunk_w0 = chunk - g;
+  if (chunk_w0 >= nchunks) return;
+  const bool active = chunk < nchunks;
+
+  const KeyT* __restrict__ skey = static_cast<const KeyT*>(a.keys_sorted);
+  const KeyT sentinel = static_cast<KeyT>((a.key_bits >= 64) ? ~0ull : ((1ull << a.key_bits) - 1ull));
+  const bool nobag = a.pooling_mode == TBE_POOL_NONE;
+  const bool mean = a.pooling_mode == TBE_POOL_MEAN;
+
+  const int64_t i0 = active ? chunk * a.C : 0;
+  const int64_t i1 = active ? min(a.N, i0 + static_cast<int64_t>(a.C)) : 0;
+  bool started_here = true;
+  if (active && i0 > 0) started_here = skey[i0 - 1] != skey[i0];
+  bool tail_open = false;  // last processed contribution did not end its run
+
+  float4 acc[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  // The loop trip count must be wave-uniform for the shuffles: use the max span over groups.
+  const int span = static_cast<int>(i1 - i0);
+  int max_span = span;
+#pragma unroll
+  for (int o = 32; o >= G; o >>= 1) max_span = max(max_span, __shfl_xor(max_span, o, kWave));
+
+  for (int sb = 0; sb < max_span; sb += G) {
+    const int64_t kk = i0 + sb + gl;
+    const bool in = active && kk < i1;
+    KeyT key_k = sentinel;
+    KeyT keyn_k = sentinel;
+    uint64_t pay_k = 0;
+    if (in) {
+      key_k = skey[kk];
+      pay_k = a.payload_sorted[kk];
+      if (kk + 1 < a.N) keyn_k = skey[kk + 1];
+    }
+    const bool valid_k = in && key_k != sentinel;
+    const bool last_k = valid_k && (key_k != keyn_k || kk + 1 >= a.N);
+    const uint32_t bag_k = static_cast<uint32_t>(pay_k >> 32);
+    const uint32_t pos_k = static_cast<uint32_t>(pay_k);
+    const int f_k = valid_k ? static_cast<int>(bag_k / static_cast<uint32_t>(a.B)) : 0;
+    const int b_k = static_cast<int>(bag_k - static_cast<uint32_t>(f_k) * static_cast<uint32_t>(a.B));
+    const int D_k = a.feat_D[f_k];
+    float w_k = 1.f;
+    const float* gptr_k = a.grad_out;
+    const float* wptr_k = nullptr;
+    int64_t lrow_k = 0;
+    if (valid_k) {
+      if (a.psw != nullptr) w_k = a.psw[pos_k];
+      if (mean) {
+        const int64_t len = a.offsets[bag_k + 1] - a.offsets[bag_k];
+        w_k = w_k / static_cast<float>(len);
+      }
+      gptr_k = nobag ? a.grad_out + static_cast<int64_t>(pos_k) * a.grad_stride
+                     : a.grad_out + static_cast<int64_t>(b_k) * a.grad_stride + a.feat_D_offset[f_k];
+      lrow_k = static_cast<int64_t>(key_k) - a.feat_row_base[f_k];
+      wptr_k = reinterpret_cast<const float*>(a.feat_weights[f_k]) + lrow_k * D_k;
+    }
+    const int n = active ? static_cast<int>(min<int64_t>(G, i1 - (i0 + sb))) : 0;
+    int max_n = n;
+#pragma unroll
+    for (int o = 32; o >= G; o >>= 1) max_n = max(max_n, __shfl_xor(max_n, o, kWave));
+
+    for (int j = 0; j < max_n; j += U) {
+      float4 x[U][NV];
+      float4 wr[U][NV];
+      float wt[U];
+      bool val[U], lst[U];
+      const float* wp[U];
+      int Du[U], fu[U];
+      int64_t lrow[U];
+      bool vecu[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int src = gbase + ((j + u) & (G - 1));
+        const bool inb = (j + u) < n;
+        val[u] = inb && (__shfl(static_cast<int>(valid_k), src, kWave) != 0);
+        lst[u] = inb && (__shfl(static_cast<int>(last_k), src, kWave) != 0);
+        wt[u] = __shfl(w_k, src, kWave);
+        const float* gp = reinterpret_cast<const float*>(shflu64(reinterpret_cast<uint64_t>(gptr_k), src));
+        wp[u] = reinterpret_cast<const float*>(shflu64(reinterpret_cast<uint64_t>(wptr_k), src));
+        Du[u] = __shfl(D_k, src, kWave);
+        fu[u] = __shfl(f_k, src, kWave);
+        lrow[u] = shfl64(lrow_k, src);
+        const bool gvec = ((Du[u] & 3) == 0) && ((reinterpret_cast<uintptr_t>(gp) & 15) == 0);
+        vecu[u] = ((Du[u] & 3) == 0) && ((reinterpret_cast<uintptr_t>(wp[u]) & 15) == 0);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          const int d = (v * G + gl) * 4;
+          x[u][v] = (val[u] && d < Du[u]) ? ldc(gp, d, Du[u], gvec) : make_float4(0.f, 0.f, 0.f, 0.f);
+          wr[u][v] = (lst[u] && d < Du[u]) ? ldc(wp[u], d, Du[u], vecu[u]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (val[u]) {
+#pragma unroll
+          for (int v = 0; v < NV; ++v) {
+            acc[v].x = fmaf(wt[u], x[u][v].x, acc[v].x);
+            acc[v].y = fmaf(wt[u], x[u][v].y, acc[v].y);
+            acc[v].z = fmaf(wt[u], x[u][v].z, acc[v].z);
+            acc[v].w = fmaf(wt[u], x[u][v].w, acc[v].w);
+          }
+          tail_open = !lst[u];
+          if (lst[u]) {
+            if (started_here) {
+              apply_row<G, NV>(a, fu[u], lrow[u], Du[u], vecu[u], gl, const_cast<float*>(wp[u]), wr[u], acc);
+            } else {
+              float* pf = a.partial_first + chunk * a.max_D_pad;
+#pragma unroll
+              for (int v = 0; v < NV; ++v) {
+                const int d = (v * G + gl) * 4;
+                if (d < Du[u]) st4(pf + d, acc[v]);
+              }
+            }
+#pragma unroll
+            for (int v = 0; v < NV; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+            started_here = true;
+          }
+        }
+      }
+    }
+  }
+  if (active) {
+    int is_origin = 0;
+    if (tail_open) {
+      float* dst = started_here ? a.partial_last + chunk * a.max_D_pad : a.partial_first + chunk * a.max_D_pad;
+      is_origin = started_here ? 1 : 0;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int d = (v * G + gl) * 4;
+        if (d < a.max_D_pad) st4(dst + d, acc[v]);
+      }
+    }
+    if (gl == 0) a.origin[chunk] = is_origin;
+  }
+}
+
+// One group per chunk: chunks flagged `origin` own a run that crosses into later chunks.
+template <typename KeyT, int G, int NV>
+__global__ __launch_bounds__(256) void bwd_fixup_kernel(BwdArgs a) {
+  constexpr int NG = kWave / G;
+  const int lane = threadIdx.x & 63;
+  const int g = lane / G;
+  const int gl = lane % G;
+  const int64_t nchunks = (a.N + a.C - 1) / a.C;
+  const int64_t chunk = (static_cast<int64_t>(blockIdx.x) * (blockDim.x / kWave) + (threadIdx.x >> 6)) * NG + g;
+  if (chunk >= nchunks) return;  // no cross-lane ops below except group_sum inside apply_row
+  const bool is_origin = a.origin[chunk] != 0;
+  // group_sum uses xor-shuffles within the group only; groups diverge freely.
+  if (!is_origin) return;
+  const KeyT* __restrict__ skey = static_cast<const KeyT*>(a.keys_sorted);
+  const int64_t last_i = (chunk + 1) * a.C - 1;  // an origin chunk is always full
+  const KeyT key_run = skey[last_i];
+  const uint64_t pay = a.payload_sorted[last_i];
+  const uint32_t bag = static_cast<uint32_t>(pay >> 32);
+  const int f = static_cast<int>(bag / static_cast<uint32_t>(a.B));
+  const int D = a.feat_D[f];
+  const int64_t lrow = static_cast<int64_t>(key_run) - a.feat_row_base[f];
+  float* wrow = reinterpret_cast<float*>(a.feat_weights[f]) + lrow * D;
+  const bool vec = ((D & 3) == 0) && ((reinterpret_cast<uintptr_t>(wrow) & 15) == 0);
+
+  float4 acc[NV], w[NV];
+  const float* pl = a.partial_last + chunk * a.max_D_pad;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int d = (v * G + gl) * 4;
+    acc[v] = (d < D) ? ld4(pl + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+    w[v] = (d < D) ? ldc(wrow, d, D, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  int64_t cc = chunk + 1;
+  while (cc < nchunks) {
+    const float* pf = a.partial_first + cc * a.max_D_pad;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int d = (v * G + gl) * 4;
+      if (d < D) {
+        const float4 o = ld4(pf + d);
+        acc[v].x += o.x;
+        acc[v].y += o.y;
+        acc[v].z += o.z;
+        acc[v].w += o.w;
+      }
+    }
+    const int64_t nx = (cc + 1) * a.C;
+    if (nx >= a.N || skey[nx] != key_run) break;
+    ++cc;
+  }
+  apply_row<G, NV>(a, f, lrow, D, vec, gl, wrow, w, acc);
+}
+
+static int pick_chunk(int64_t N) {
+  int64_t c = (N + 16383) / 16384;
+  c = (c + 31) / 32 * 32;
+  if (c < 32) c = 32;
+  if (c > 256) c = 256;
+  return static_cast<int>(c);
+}
+
+struct BwdWorkspace {
+  void* keys_in;
+  void* keys_out;
+  uint64_t* pay_in;
+  uint64_t* pay_out;
+  float* partial_first;
+  float* partial_last;
+  int32_t* origin;
+  void* sort_tmp;
+  size_t sort_tmp_bytes;
+  size_t total;
+};
+
+template <typename KeyT>
+static hipError_t sort_pairs(void* tmp, size_t& tmp_bytes, KeyT* kin, KeyT* kout, uint64_t* vin,
+                             uint64_t* vout, int64_t N, int key_bits, hipStream_t st) {
+  return rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, static_cast<size_t>(N), 0u,
+                                   static_cast<unsigned>(key_bits), st, false);
+}
+
+static int carve(void* ws, int64_t N, int32_t max_D, int32_t key_bits, BwdWorkspace* out) {
+  const bool k64 = key_bits > 32;
+  const size_t ksz = k64 ? 8 : 4;
+  const int C = pick_chunk(N);
+  const int64_t nchunks = (N + C - 1) / C;
+  const int max_D_pad = (max_D + 3) / 4 * 4;
+  size_t sort_bytes = 0;
+  hipError_t e = k64 ? sort_pairs<uint64_t>(nullptr, sort_bytes, nullptr, nullptr, nullptr, nullptr, N, key_bits, nullptr)
+                     : sort_pairs<uint32_t>(nullptr, sort_bytes, nullptr, nullptr, nullptr, nullptr, N, key_bits, nullptr);
+  if (e != hipSuccess) {
+    set_error("rocprim radix_sort_pairs size query failed: %s", hipGetErrorString(e));
+    return TBE_ERR_LAUNCH;
+  }
+  Carver c(ws);
+  out->keys_in = c.take_bytes(N * ksz);
+  out->keys_out = c.take_bytes(N * ksz);
+  out->pay_in = c.take<uint64_t>(N);
+  out->pay_out = c.take<uint64_t>(N);
+  out->partial_first = c.take<float>(nchunks * max_D_pad);
+  out->partial_last = c.take<float>(nchunks * max_D_pad);
+  out->origin = c.take<int32_t>(nchunks);
+  out->sort_tmp = c.take_bytes(sort_bytes);
+  out->sort_tmp_bytes = sort_bytes;
+  out->total = c.total();
+  return TBE_OK;
+}
+
+template <typename KeyT, int G, int NV>
+static int launch_update(const BwdArgs& a, hipStream_t st) {
+  constexpr int NG = kWave / G;
+  const int64_t nchunks = (a.N + a.C - 1) / a.C;
+  const int64_t groups_per_block = 4 * NG;
+  const unsigned grid = static_cast<unsigned>((nchunks + groups_per_block - 1) / groups_per_block);
+  hipLaunchKernelGGL((bwd_update_kernel<KeyT, G, NV>), dim3(grid), dim3(256), 0, st, a);
+  TBE_CHECK_LAUNCH("tbe_backward update");
+  hipLaunchKernelGGL((bwd_fixup_kernel<KeyT, G, NV>), dim3(grid), dim3(256), 0, st, a);
+  TBE_CHECK_LAUNCH("tbe_backward fixup");
+  return TBE_OK;
+}
+
+template <typename KeyT>
+static int run_backward(BwdArgs a, const BwdWorkspace& w, int32_t max_D, hipStream_t st) {
+  KeyT* kin = static_cast<KeyT*>(w.keys_in);
+  KeyT* kout = static_cast<KeyT*>(w.keys_out);
+  if (a.pooling_mode == TBE_POOL_NONE) {
+    const size_t lds = (static_cast<size_t>(a.F) + 1) * sizeof(int64_t);
+    const unsigned grid = static_cast<unsigned>(std::min<int64_t>((a.N + 255) / 256, 256 * 16));
+    hipLaunchKernelGGL((bwd_linearize_nobag_kernel<KeyT>), dim3(grid), dim3(256), lds, st, a.indices,
+                       a.offsets, a.feat_rows, a.feat_row_base, a.F, a.B, a.N, a.key_bits, kin,
+                       w.pay_in, a.bounds_errors);
+  } else {
+    const int64_t nbags = static_cast<int64_t>(a.F) * a.B;
+    const unsigned grid = static_cast<unsigned>((nbags + 255) / 256);
+    hipLaunchKernelGGL((bwd_linearize_pooled_kernel<KeyT>), dim3(grid), dim3(256), 0, st, a.indices,
+                       a.offsets, a.feat_rows, a.feat_row_base, a.F, a.B, a.key_bits, kin, w.pay_in,
+                       a.bounds_errors);
+  }
+  TBE_CHECK_LAUNCH("tbe_backward linearize");
+  size_t tmp_bytes = w.sort_tmp_bytes;
+  hipError_t e = sort_pairs<KeyT>(w.sort_tmp, tmp_bytes, kin, kout, w.pay_in, w.pay_out, a.N, a.key_bits, st);
+  if (e != hipSuccess) {
+    set_error("tbe_backward: radix sort failed: %s", hipGetErrorString(e));
+    return TBE_ERR_LAUNCH;
+  }
+  a.keys_sorted = kout;
+  a.payload_sorted = w.pay_out;
+  if (max_D <= 64) return launch_update<KeyT, 16, 1>(a, st);
+  if (max_D <= 128) return launch_update<KeyT, 32, 1>(a, st);
+  if (max_D <= 256) return launch_update<KeyT, 64, 1>(a, st);
+  if (max_D <= 512) return launch_update<KeyT, 64, 2>(a, st);
+  if (max_D <= 1024) return launch_update<KeyT, 64, 4>(a, st);
+  return launch_update<KeyT, 64, 8>(a, st);
+}
+
+}  // namespace tbe
+
+using namespace tbe;
+
+extern "C" size_t tbe_backward_workspace_bytes(int64_t N, int32_t F, int32_t B, int32_t max_D,
+                                               int32_t key_bits) {
+  (void)F;
+  (void)B;
+  if (N <= 0) return 256;
+  BwdWorkspace w;
+  if (carve(nullptr, N, max_D, key_bits, &w) != TBE_OK) return 0;
+  return w.total;
+}
+
+extern "C" int tbe_backward_fused_f32(
+    const uint64_t* feat_weights, const int32_t* feat_D, const int32_t* feat_D_offset,
+    const int64_t* feat_rows, const int64_t* feat_row_base, const uint64_t* feat_state0,
+    const uint64_t* feat_state1, int32_t F, int32_t B, int32_t total_D, int32_t max_D,
+    int32_t key_bits, const int64_t* indices, int64_t N, const int64_t* offsets,
+    const float* per_sample_weights, int32_t pooling_mode, const float* grad_out,
+    int64_t grad_row_stride, tbe_optimizer_args opt, void* workspace, size_t workspace_bytes,
+    int32_t* bounds_errors, void* stream) {
+  TBE_REQUIRE(F > 0 && B >= 0 && N >= 0, "tbe_backward_fused_f32: bad sizes");
+  TBE_REQUIRE(max_D > 0 && max_D <= 2048, "tbe_backward_fused_f32: max_D=%d outside (0, 2048]", max_D);
+  TBE_REQUIRE(key_bits >= 1 && key_bits <= 64, "tbe_backward_fused_f32: key_bits=%d", key_bits);
+  TBE_REQUIRE(pooling_mode == TBE_POOL_SUM || pooling_mode == TBE_POOL_MEAN || pooling_mode == TBE_POOL_NONE,
+              "tbe_backward_fused_f32: pooling_mode %d", pooling_mode);
+  TBE_REQUIRE(static_cast<int64_t>(F) * B < (1ll << 32) && N < (1ll << 32),
+              "tbe_backward_fused_f32: F*B and N must be < 2^32");
+  if (pooling_mode != TBE_POOL_NONE) TBE_REQUIRE(grad_row_stride >= total_D, "tbe_backward_fused_f32: grad_row_stride < total_D");
+  switch (opt.optimizer) {
+    case TBE_OPT_EXACT_SGD:
+      break;
+    case TBE_OPT_EXACT_ROWWISE_ADAGRAD:
+    case TBE_OPT_EXACT_ADAGRAD:
+    case TBE_OPT_DENSE_GRAD:
+      TBE_REQUIRE(feat_state0 != nullptr, "tbe_backward_fused_f32: optimizer %d needs feat_state0", opt.optimizer);
+      break;
+    case TBE_OPT_ADAM:
+      TBE_REQUIRE(feat_state0 != nullptr && feat_state1 != nullptr, "tbe_backward_fused_f32: ADAM needs two states");
+      TBE_REQUIRE(opt.iteration >= 1, "tbe_backward_fused_f32: ADAM iteration must be >= 1");
+      break;
+    default:
+      set_error("tbe_backward_fused_f32: unknown optimizer %d", opt.optimizer);
+      return TBE_ERR_UNSUPPORTED;
+  }
+  if (N == 0 || B == 0) return TBE_OK;
+  TBE_REQUIRE(feat_weights && feat_D && feat_D_offset && feat_rows && feat_row_base && indices && offsets && grad_out && workspace,
+              "tbe_backward_fused_f32: null pointer");
+  TBE_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "tbe_backward_fused_f32: workspace must be 256-B aligned");
+  BwdWorkspace w;
+  int rc = carve(workspace, N, max_D, key_bits, &w);
+  if (rc != TBE_OK) return rc;
+  if (w.total > workspace_bytes) {
+    set_error("tbe_backward_fused_f32: workspace too small (%zu < %zu)", workspace_bytes, w.total);
+    return TBE_ERR_WORKSPACE;
+  }
+  BwdArgs a{};
+  a.feat_weights = feat_weights;
+  a.feat_D = feat_D;
+  a.feat_D_offset = feat_D_offset;
+  a.feat_rows = feat_rows;
+  a.feat_row_base = feat_row_base;
+  a.feat_state0 = feat_state0;
+  a.feat_state1 = feat_state1;
+  a.indices = indices;
+  a.offsets = offsets;
+  a.psw = per_sample_weights;
+  a.grad_out = grad_out;
+  a.grad_stride = grad_row_stride;
+  a.N = N;
+  a.F = F;
+  a.B = B;
+  a.pooling_mode = pooling_mode;
+  a.key_bits = key_bits;
+  a.C = pick_chunk(N);
+  a.opt = opt;
+  a.bias1 = 1.f;
+  a.bias2 = 1.f;
+  if (opt.optimizer == TBE_OPT_ADAM) {
+    a.bias1 = 1.f - powf(opt.beta1, static_cast<float>(opt.iteration));
+    a.bias2 = 1.f - powf(opt.beta2, static_cast<float>(opt.iteration));
+  }
+  a.partial_first = w.partial_first;
+  a.partial_last = w.partial_last;
+  a.origin = w.origin;
+  a.max_D_pad = (max_D + 3) / 4 * 4;
+  a.bounds_errors = bounds_errors;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (key_bits > 32) return run_backward<uint64_t>(a, w, max_D, st);
+  return run_backward<uint32_t>(a, w, max_D, st);
+}

@@ -1,0 +1,149 @@
+"""ctypes binding of the gfx950 C-ABI library declared in ``include/tbe_hip.h``.
+
+This is the host side of the drop-in boundary: the library is built in-tree by
+``__graft_entry__.build()`` (``torchrec-oldfork_amd/csrc/Makefile``) and loaded here.
+There is NO fallback: if the shared object is missing, import fails loudly; if it is
+called with non-device tensors, the wrappers raise.
+"""
+import ctypes
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "lib", "libtbe_hip.so"))
+
+c_void_p = ctypes.c_void_p
+c_i32 = ctypes.c_int32
+c_i64 = ctypes.c_int64
+c_size = ctypes.c_size_t
+c_float = ctypes.c_float
+
+
+class OptimizerArgs(ctypes.Structure):
+    """Mirror of ``tbe_optimizer_args`` (include/tbe_hip.h)."""
+
+    _fields_ = [
+        ("optimizer", c_i32),
+        ("learning_rate", c_float),
+        ("eps", c_float),
+        ("weight_decay", c_float),
+        ("beta1", c_float),
+        ("beta2", c_float),
+        ("iteration", c_i64),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol of include/tbe_hip.h
+SIGNATURES = {
+    "tbe_last_error": (ctypes.c_char_p, []),
+    "tbe_abi_version": (c_i32, []),
+    "tbe_forward_pooled_f32": (
+        ctypes.c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_i32, c_i32, c_void_p, c_i64,
+         c_void_p, c_void_p, c_i32, c_void_p, c_i64, c_void_p, c_void_p],
+    ),
+    "tbe_forward_nobag_f32": (
+        ctypes.c_int,
+        [c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p, c_i64, c_void_p, c_void_p, c_void_p,
+         c_void_p],
+    ),
+    "tbe_backward_workspace_bytes": (c_size, [c_i64, c_i32, c_i32, c_i32, c_i32]),
+    "tbe_backward_fused_f32": (
+        ctypes.c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_i32,
+         c_i32, c_i32, c_void_p, c_i64, c_void_p, c_void_p, c_i32, c_void_p, c_i64, OptimizerArgs,
+         c_void_p, c_size, c_void_p, c_void_p],
+    ),
+    "tbe_cumsum_workspace_bytes": (c_size, [c_i64]),
+    "tbe_cumsum": (ctypes.c_int, [c_void_p, c_void_p, c_i64, c_i32, c_i32, c_void_p, c_size, c_void_p]),
+    "tbe_permute_2d_workspace_bytes": (c_size, [c_i32, c_i32, c_i32]),
+    "tbe_permute_2d_lengths": (
+        ctypes.c_int,
+        [c_void_p, c_i32, c_i32, c_i32, c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_void_p,
+         c_size, c_void_p],
+    ),
+    "tbe_permute_2d_data": (
+        ctypes.c_int,
+        [c_void_p, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_void_p, c_void_p,
+         c_i32, c_void_p],
+    ),
+    "tbe_bucketize_workspace_bytes": (c_size, [c_i64, c_i32]),
+    "tbe_block_bucketize": (
+        ctypes.c_int,
+        [c_void_p, c_i32, c_i64, c_void_p, c_i32, c_i64, c_void_p, c_i32, c_i32, c_void_p, c_i32,
+         c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size, c_void_p],
+    ),
+    "tbe_a2a_pooled_unpack": (
+        ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_i32, c_i32, c_float, c_void_p]),
+    "tbe_a2a_pooled_pack": (
+        ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_i32, c_i32, c_float, c_void_p]),
+    "tbe_jagged_2d_to_dense_f32": (
+        ctypes.c_int, [c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p, c_void_p]),
+    "tbe_offsets_range": (ctypes.c_int, [c_void_p, c_i64, c_i64, c_void_p, c_void_p]),
+}
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def load() -> ctypes.CDLL:
+    """Loads the in-tree HIP library; raises ImportError (never falls back) if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the MI355X HIP extension has not been built. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` at the repo root "
+            "(or `make -C torchrec-oldfork_amd/csrc`). There is no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().tbe_last_error()
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    """Device address of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def require_gpu(*tensors: Optional[torch.Tensor]) -> torch.device:
+    """All given tensors must live on one HIP device; returns it."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "fbgemm_gpu (MI355X build): tensor on device "
+                f"'{t.device}' — this path only runs on a HIP device; there is no CPU fallback"
+            )
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"tensors on different devices: {dev} vs {t.device}")
+    if dev is None:
+        raise RuntimeError("no tensor given")
+    return dev
+
+
+def stream_ptr(dev: torch.device) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def workspace(nbytes: int, dev: torch.device) -> torch.Tensor:
+    """256-B aligned scratch from the caching allocator (stream-ordered on the current stream)."""
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
