@@ -1,0 +1,135 @@
+"""GPU parity (bit-exact): torch.ops.fbgemm.* index ops on HIP vs the oracle, the reference's
+known answers and the reference-generated golden vectors."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import _paths  # noqa: F401
+import fbgemm_gpu  # noqa: F401
+from fbgemm_gpu import _lib
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def cu(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return (t.to(dtype) if dtype is not None else t).cuda()
+
+
+@pytest.mark.parametrize("dtype", [np.int32, np.int64])
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 255, 256, 2047, 2048, 2049, 26 * 4096, 1000003, 26 * 65536])
+def test_cumsum(dtype, n):
+    rng = np.random.default_rng(n)
+    x = rng.integers(0, 100, size=n).astype(dtype)
+    out = torch.ops.fbgemm.asynchronous_complete_cumsum(cu(x))
+    np.testing.assert_array_equal(out.cpu().numpy(), oracle.cumsum(x, 0))
+    np.testing.assert_array_equal(torch.ops.fbgemm.asynchronous_inclusive_cumsum(cu(x)).cpu().numpy(), oracle.cumsum(x, 1))
+    np.testing.assert_array_equal(torch.ops.fbgemm.asynchronous_exclusive_cumsum(cu(x)).cpu().numpy(), oracle.cumsum(x, 2))
+
+
+def test_cumsum_int32_wraps_like_int32():
+    x = np.full(5, 2**30, dtype=np.int32)
+    out = torch.ops.fbgemm.asynchronous_complete_cumsum(cu(x)).cpu().numpy()
+    np.testing.assert_array_equal(out, oracle.cumsum(x, 0))
+
+
+def test_permute_reference_known_answers():
+    # torchrec/sparse/tests/test_jagged_tensor.py:632-755
+    values = cu(np.array([1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 7.0, 8.0], dtype=np.float32))
+    weights = cu(np.array([1.0, 0.5, 1.5, 1.0, 0.5, 1.0, 1.0, 1.5], dtype=np.float32))
+    lengths = cu(np.array([0, 2, 0, 1, 1, 1, 0, 3, 0], dtype=np.int32)).view(3, 3)
+    l, v, w = torch.ops.fbgemm.permute_2D_sparse_data(cu(np.array([1, 0, 2], dtype=np.int32)), lengths, values, weights)
+    assert l.view(-1).tolist() == [1, 1, 1, 0, 2, 0, 0, 3, 0]
+    assert v.tolist() == [3.0, 4.0, 5.0, 1.0, 2.0, 6.0, 7.0, 8.0]
+    assert w.tolist() == [1.5, 1.0, 0.5, 1.0, 0.5, 1.0, 1.0, 1.5]
+    l, v, w = torch.ops.fbgemm.permute_2D_sparse_data(cu(np.array([1, 0, 2, 1, 1], dtype=np.int32)), lengths, values, None, 14)
+    assert l.view(-1).tolist() == [1, 1, 1, 0, 2, 0, 0, 3, 0, 1, 1, 1, 1, 1, 1]
+    assert v.tolist() == [3.0, 4.0, 5.0, 1.0, 2.0, 6.0, 7.0, 8.0, 3.0, 4.0, 5.0, 3.0, 4.0, 5.0]
+    assert w is None
+
+
+@pytest.mark.parametrize("T,B,maxlen,vdtype,ldtype", [
+    (1, 1, 3, np.int64, np.int32), (3, 7, 4, np.int64, np.int32), (26, 300, 2, np.int64, np.int32),
+    (8, 65, 9, np.float32, np.int64), (5, 64, 0, np.int32, np.int32), (4, 129, 200, np.int64, np.int32),
+    (26, 4096, 1, np.int64, np.int32), (3, 10, 5, np.float64, np.int32), (2, 100, 3, np.int16, np.int32),
+])
+def test_permute_vs_oracle(T, B, maxlen, vdtype, ldtype):
+    rng = np.random.default_rng(T * 1000 + B)
+    lengths = rng.integers(0, maxlen + 1, size=(T, B)).astype(ldtype)
+    N = int(lengths.sum())
+    values = (rng.integers(0, 1 << 15, size=N)).astype(vdtype)
+    weights = rng.random(N).astype(np.float32)
+    perm = rng.integers(0, T, size=T + 2).astype(np.int32)  # duplicates allowed, T' != T
+    l, v, w = torch.ops.fbgemm.permute_2D_sparse_data(cu(perm), cu(lengths), cu(values), cu(weights))
+    el, ev, ew = oracle.permute_2d(perm, lengths, values, weights)
+    np.testing.assert_array_equal(l.cpu().numpy(), el)
+    np.testing.assert_array_equal(v.cpu().numpy(), ev)
+    np.testing.assert_array_equal(w.cpu().numpy(), ew)
+
+
+BUCK = sorted(glob.glob(os.path.join(GOLD, "bucketize_*.npz")))
+
+
+@pytest.mark.parametrize("path", BUCK, ids=[os.path.basename(p) for p in BUCK])
+def test_bucketize_reference_golden(path):
+    g = np.load(path)
+    nl, ni, nw, npos, unb = torch.ops.fbgemm.block_bucketize_sparse_features(
+        cu(g["lengths"]), cu(g["values"]), False, False, cu(g["block_sizes"]), int(g["W"]), cu(g["weights"]))
+    np.testing.assert_array_equal(nl.cpu().numpy(), g["exp_lengths"])
+    np.testing.assert_array_equal(ni.cpu().numpy(), g["exp_values"])
+    np.testing.assert_array_equal(nw.cpu().numpy(), g["exp_weights"])
+    assert npos is None and unb is None
+
+
+@pytest.mark.parametrize("F,B,W,maxlen,idt,ldt", [
+    (1, 1, 1, 3, np.int64, np.int32), (3, 50, 8, 6, np.int64, np.int32), (26, 1024, 8, 1, np.int64, np.int32),
+    (4, 33, 129, 10, np.int32, np.int64), (2, 700, 2, 30, np.int32, np.int32), (5, 9, 3, 0, np.int64, np.int64),
+])
+def test_bucketize_vs_oracle_with_pos_and_sequence(F, B, W, maxlen, idt, ldt):
+    rng = np.random.default_rng(F * 100 + B + W)
+    lengths = rng.integers(0, maxlen + 1, size=F * B).astype(ldt)
+    N = int(lengths.sum())
+    rows = rng.integers(W, 5000, size=F)
+    blocks = ((rows + W - 1) // W).astype(idt)
+    feat_of = np.repeat(np.arange(F), B).repeat(lengths)
+    indices = (rng.random(N) * rows[feat_of]).astype(idt) if N else np.zeros(0, idt)
+    weights = rng.random(N).astype(np.float32)
+    got = torch.ops.fbgemm.block_bucketize_sparse_features(cu(lengths), cu(indices), True, True, cu(blocks), W, cu(weights))
+    exp = oracle.block_bucketize(lengths, indices, blocks, W, weights, True, True)
+    for a, b in zip(got, exp):
+        np.testing.assert_array_equal(a.cpu().numpy(), b)
+
+
+def test_a2a_pooled_layout_vs_oracle():
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    for dims, Bl in [([128, 384, 512], 64), ([8, 4, 12, 20], 33), ([3, 5], 7), ([128] * 8, 256)]:
+        D = sum(dims)
+        dims_d = cu(np.array(dims, dtype=np.int32))
+        grad = rng.standard_normal((Bl, D)).astype(np.float32)
+        send = torch.empty(Bl * D, dtype=torch.float32, device="cuda")
+        vec = int(all(d % 4 == 0 for d in dims))
+        st = torch.cuda.current_stream().cuda_stream
+        _lib.check(lib.tbe_a2a_pooled_pack(cu(grad).data_ptr(), send.data_ptr(), dims_d.data_ptr(), len(dims), Bl, D, vec, 0.5, st), "pack")
+        np.testing.assert_array_equal(send.cpu().numpy(), oracle.a2a_pooled_pack(grad, dims, 0.5))
+        out = torch.empty((Bl, D), dtype=torch.float32, device="cuda")
+        _lib.check(lib.tbe_a2a_pooled_unpack(send.data_ptr(), out.data_ptr(), dims_d.data_ptr(), len(dims), Bl, D, vec, 2.0, st), "unpack")
+        np.testing.assert_array_equal(out.cpu().numpy(), grad)  # 0.5 * 2.0 round trip is exact
+
+
+def test_offsets_range_and_jagged_2d_to_dense():
+    rng = np.random.default_rng(1)
+    lengths = rng.integers(0, 9, size=50)
+    offsets = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+    N = int(offsets[-1])
+    r = torch.ops.fbgemm.offsets_range(cu(offsets[:-1]), N)
+    np.testing.assert_array_equal(r.cpu().numpy(), oracle.offsets_range(offsets[:-1], N))
+    values = rng.standard_normal((N, 24)).astype(np.float32)
+    for max_l in (1, 5, 12):
+        d = torch.ops.fbgemm.jagged_2d_to_dense(cu(values), cu(offsets), max_l)
+        np.testing.assert_array_equal(d.cpu().numpy(), oracle.jagged_2d_to_dense(values, offsets, max_l))

@@ -1,0 +1,280 @@
+"""GPU parity: HIP TBE forward / backward+fused optimizer (through the fbgemm_gpu module surface
+and the C ABI) against the CPU oracle and the reference-generated golden vectors.
+
+Tolerances: pooling factor 1 / duplicate-free cases are bit-exact; sums of several rows are
+compared at the reference's own tolerance (torch.testing.assert_allclose fp32 defaults,
+rtol 1.3e-6, atol 1e-5 — SURVEY.md §8c), scaled for long sums where stated."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import _paths  # noqa: F401
+from _util import build_pair, make_inputs, to_dev
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+RTOL, ATOL = 1.3e-6, 1e-5
+
+
+def _opt(name):
+    from fbgemm_gpu.split_embedding_configs import EmbOptimType
+    return getattr(EmbOptimType, name)
+
+
+def run_fwd(mod, indices, offsets, psw):
+    out = mod(to_dev(indices), to_dev(offsets), to_dev(psw))
+    torch.cuda.synchronize()
+    return out
+
+
+EBC = sorted(glob.glob(os.path.join(GOLD, "ebc_*.npz")))
+
+
+@pytest.mark.parametrize("path", EBC, ids=[os.path.basename(p) for p in EBC])
+def test_golden_forward_backward_sgd(path):
+    """HIP vs the REFERENCE's EmbeddingBagCollection + torch.optim.SGD (golden vectors)."""
+    g = np.load(path)
+    rows, dims = g["rows"].tolist(), g["dims"].tolist()
+    pooling = 1 if str(g["pooling"]) == "mean" else 0
+    mod, tabs = build_pair(rows, dims, None, pooling, learning_rate=float(g["lr"]))
+    for t, w in enumerate(mod.split_embedding_weights()):
+        w.copy_(torch.from_numpy(g[f"w_before_{t}"]))
+    psw = g["weights"] if "weights" in g else None
+    out = run_fwd(mod, g["values"], g["offsets"], psw)
+    if "l1_sum" in path:
+        np.testing.assert_array_equal(out.detach().cpu().numpy(), g["out"])
+    else:
+        np.testing.assert_allclose(out.detach().cpu().numpy(), g["out"], rtol=RTOL, atol=ATOL)
+    out.backward(to_dev(g["grad_out"]))
+    torch.cuda.synchronize()
+    for t, w in enumerate(mod.split_embedding_weights()):
+        np.testing.assert_allclose(w.cpu().numpy(), g[f"w_after_{t}"], rtol=RTOL, atol=ATOL)
+    assert mod.bounds_check_errors() == 0
+
+
+CASES = [
+    # rows, dims, ftm, B, max_len, fixed_len, weighted, pooling
+    dict(rows=[100, 7, 3000], dims=[128, 128, 128], ftm=None, B=300, max_len=1, fixed_len=1, weighted=False, pooling=0),
+    dict(rows=[50, 9], dims=[64, 32], ftm=[0, 1, 0], B=65, max_len=5, fixed_len=None, weighted=False, pooling=0),
+    dict(rows=[50, 9, 11], dims=[16, 256, 8], ftm=None, B=130, max_len=4, fixed_len=None, weighted=True, pooling=0),
+    dict(rows=[33, 200], dims=[512, 40], ftm=None, B=70, max_len=3, fixed_len=None, weighted=False, pooling=1),
+    dict(rows=[20, 15], dims=[1024, 12], ftm=None, B=19, max_len=2, fixed_len=None, weighted=True, pooling=1),
+    dict(rows=[12, 40], dims=[7, 13], ftm=None, B=37, max_len=4, fixed_len=None, weighted=False, pooling=0),  # D % 4 != 0
+    dict(rows=[64], dims=[2048], ftm=None, B=5, max_len=3, fixed_len=None, weighted=False, pooling=0),
+    dict(rows=[500, 30], dims=[128, 64], ftm=None, B=33, max_len=60, fixed_len=None, weighted=False, pooling=0),  # long-bag kernel
+    dict(rows=[500, 30], dims=[32, 256], ftm=None, B=17, max_len=70, fixed_len=None, weighted=True, pooling=1),  # long-bag, weighted mean
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[str(i) for i in range(len(CASES))])
+def test_forward_vs_oracle(case):
+    rng = np.random.default_rng(11)
+    mod, tabs = build_pair(case["rows"], case["dims"], case["ftm"], case["pooling"], rng=rng)
+    indices, offsets, psw = make_inputs(rng, case["rows"], case["B"], case["max_len"], case["ftm"],
+                                        case["fixed_len"], case["weighted"])
+    out = run_fwd(mod, indices, offsets, psw).detach().cpu().numpy()
+    ref, bad = oracle.tbe_forward(tabs, indices, offsets, psw, case["pooling"])
+    assert bad == 0 and mod.bounds_check_errors() == 0
+    long_bags = indices.size / max(1, (offsets.size - 1)) >= 12
+    if case["fixed_len"] == 1 and not case["weighted"]:
+        np.testing.assert_array_equal(out, ref)
+    elif not long_bags:
+        # same accumulation order as the oracle (sequential fmaf): bit-exact
+        np.testing.assert_array_equal(out, ref)
+    else:
+        np.testing.assert_allclose(out, ref, rtol=1e-5, atol=1e-4)  # different (fixed) association
+
+
+OPTS = [
+    ("EXACT_SGD", {}),
+    ("EXACT_ROWWISE_ADAGRAD", dict(eps=1e-3)),
+    ("EXACT_ROWWISE_ADAGRAD", dict(eps=1e-3, weight_decay=0.01)),
+    ("EXACT_ADAGRAD", dict(eps=1e-3)),
+    ("ADAM", dict(eps=1e-3, weight_decay=0.02)),
+]
+
+
+def _states(mod, tabs, code):
+    s0 = s1 = None
+    if code == oracle.OPT_EXACT_ROWWISE_ADAGRAD:
+        s0 = [np.zeros(r, dtype=np.float32) for r in tabs.rows]
+    elif code in (oracle.OPT_ADAM, oracle.OPT_EXACT_ADAGRAD):
+        s0 = [np.zeros((r, d), dtype=np.float32) for r, d in zip(tabs.rows, tabs.dims)]
+        if code == oracle.OPT_ADAM:
+            s1 = [np.zeros((r, d), dtype=np.float32) for r, d in zip(tabs.rows, tabs.dims)]
+    return s0, s1
+
+
+@pytest.mark.parametrize("optname,kw", OPTS, ids=[f"{o[0]}{i}" for i, o in enumerate(OPTS)])
+@pytest.mark.parametrize("case", CASES[:7], ids=[str(i) for i in range(7)])
+def test_backward_fused_vs_oracle(case, optname, kw):
+    rng = np.random.default_rng(5)
+    code = {"EXACT_SGD": 0, "EXACT_ROWWISE_ADAGRAD": 1, "ADAM": 2, "EXACT_ADAGRAD": 3}[optname]
+    lr = 0.05
+    mod, tabs = build_pair(case["rows"], case["dims"], case["ftm"], case["pooling"], _opt(optname), rng,
+                           learning_rate=lr, **kw)
+    s0, s1 = _states(mod, tabs, code)
+    for step in range(2):  # two steps so the optimizer state is exercised
+        indices, offsets, psw = make_inputs(rng, case["rows"], case["B"], case["max_len"], case["ftm"],
+                                            case["fixed_len"], case["weighted"])
+        out = mod(to_dev(indices), to_dev(offsets), to_dev(psw))
+        grad = rng.standard_normal(tuple(out.shape)).astype(np.float32)
+        out.backward(to_dev(grad))
+        torch.cuda.synchronize()
+        oracle.tbe_backward(tabs, indices, offsets, grad, code, lr, psw, case["pooling"],
+                            eps=kw.get("eps", 1e-8), weight_decay=kw.get("weight_decay", 0.0),
+                            iteration=step + 1, state0=s0, state1=s1)
+    for t, w in enumerate(mod.split_embedding_weights()):
+        np.testing.assert_allclose(w.cpu().numpy(), tabs.weights[t], rtol=2e-5, atol=2e-5)
+    states = mod.split_optimizer_states()
+    for t in range(len(tabs.rows)):
+        if s0 is not None:
+            np.testing.assert_allclose(states[t][0].cpu().numpy(), s0[t], rtol=2e-5, atol=2e-5)
+        if s1 is not None:
+            np.testing.assert_allclose(states[t][1].cpu().numpy(), s1[t], rtol=2e-5, atol=2e-5)
+        if code == 0:
+            assert states[t] == ()
+
+
+def test_backward_sgd_duplicate_free_is_bit_exact():
+    """With unique ids every row gets one contribution: w' = fma(-lr, g, w) exactly."""
+    rng = np.random.default_rng(2)
+    rows, dims = [5000, 3000], [128, 128]
+    B = 512
+    mod, tabs = build_pair(rows, dims, None, 0, rng=rng, learning_rate=0.3)
+    indices = np.concatenate([rng.permutation(rows[0])[:B], rng.permutation(rows[1])[:B]]).astype(np.int64)
+    offsets = np.arange(2 * B + 1, dtype=np.int64)
+    out = mod(to_dev(indices), to_dev(offsets))
+    grad = rng.standard_normal(tuple(out.shape)).astype(np.float32)
+    out.backward(to_dev(grad))
+    torch.cuda.synchronize()
+    oracle.tbe_backward(tabs, indices, offsets, grad, oracle.OPT_EXACT_SGD, 0.3)
+    for t, w in enumerate(mod.split_embedding_weights()):
+        np.testing.assert_array_equal(w.cpu().numpy(), tabs.weights[t])
+
+
+def test_backward_heavy_duplicates_small_tables_and_determinism():
+    """Criteo-like skew: tables with 3 / 4 / 10 rows receive B contributions each -> runs far
+    longer than a chunk (fix-up path).  Also: two runs give bitwise identical weights."""
+    rows, dims = [3, 4, 10, 100000], [128, 128, 128, 128]
+    B = 4096
+    results = []
+    for rep in range(2):
+        rng = np.random.default_rng(9)
+        mod, tabs = build_pair(rows, dims, None, 0, rng=rng, learning_rate=0.01)
+        indices, offsets, _ = make_inputs(rng, rows, B, 1, fixed_len=1)
+        out = mod(to_dev(indices), to_dev(offsets))
+        grad = rng.standard_normal(tuple(out.shape)).astype(np.float32)
+        out.backward(to_dev(grad))
+        torch.cuda.synchronize()
+        results.append([w.cpu().numpy().copy() for w in mod.split_embedding_weights()])
+        if rep == 0:
+            oracle.tbe_backward(tabs, indices, offsets, grad, oracle.OPT_EXACT_SGD, 0.01)
+            for t in range(len(rows)):
+                # ~1400 addends per row for the tiny tables: tolerance scaled with sqrt(n)*eps
+                np.testing.assert_allclose(results[0][t], tabs.weights[t], rtol=1e-4, atol=2e-4)
+    for a, b in zip(*results):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_dense_variant_gradient_vs_oracle():
+    rng = np.random.default_rng(4)
+    rows, dims, ftm = [40, 11], [64, 16], [0, 1, 1]
+    mod, tabs = build_pair(rows, dims, ftm, 0, rng=rng, dense=True)
+    indices, offsets, psw = make_inputs(rng, rows, 33, 4, ftm, weighted=True)
+    out = mod(to_dev(indices), to_dev(offsets), to_dev(psw))
+    grad = rng.standard_normal(tuple(out.shape)).astype(np.float32)
+    out.backward(to_dev(grad))
+    torch.cuda.synchronize()
+    gw = [np.zeros((r, d), dtype=np.float32) for r, d in zip(rows, dims)]
+    oracle.tbe_backward(tabs, indices, offsets, grad, oracle.OPT_DENSE_GRAD, 0.0, psw, 0, state0=gw)
+    flat = mod.weights.grad.cpu().numpy()
+    for t in range(len(rows)):
+        o = mod.weights_offsets[t]
+        np.testing.assert_allclose(flat[o:o + rows[t] * dims[t]].reshape(rows[t], dims[t]), gw[t], rtol=2e-5, atol=2e-5)
+
+
+def test_nobag_forward_backward_vs_oracle():
+    rng = np.random.default_rng(6)
+    rows, dims, ftm = [30, 17], [64, 64], [0, 1, 0]
+    mod, tabs = build_pair(rows, dims, ftm, 2, _opt("ADAM"), rng, learning_rate=0.01)
+    indices, offsets, _ = make_inputs(rng, rows, 12, 5, ftm)
+    out = mod(to_dev(indices), to_dev(offsets))
+    ref, _ = oracle.tbe_forward(tabs, indices, offsets, None, oracle.POOL_NONE)
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), ref)
+    grad = rng.standard_normal(tuple(out.shape)).astype(np.float32)
+    out.backward(to_dev(grad))
+    torch.cuda.synchronize()
+    s0 = [np.zeros((r, d), dtype=np.float32) for r, d in zip(rows, dims)]
+    s1 = [np.zeros((r, d), dtype=np.float32) for r, d in zip(rows, dims)]
+    oracle.tbe_backward(tabs, indices, offsets, grad, oracle.OPT_ADAM, 0.01, None, oracle.POOL_NONE,
+                        state0=s0, state1=s1)
+    for t, w in enumerate(mod.split_embedding_weights()):
+        np.testing.assert_allclose(w.cpu().numpy(), tabs.weights[t], rtol=2e-5, atol=2e-5)
+
+
+def test_out_of_range_indices_are_counted_and_contribute_zero():
+    rng = np.random.default_rng(8)
+    rows, dims = [10, 20], [32, 32]
+    mod, tabs = build_pair(rows, dims, None, 0, rng=rng)
+    B = 8
+    indices = rng.integers(0, 10, size=2 * B).astype(np.int64)
+    indices[3] = 10      # == rows -> invalid
+    indices[B + 1] = -1  # negative -> invalid
+    offsets = np.arange(2 * B + 1, dtype=np.int64)
+    out = mod(to_dev(indices), to_dev(offsets))
+    ref, bad = oracle.tbe_forward(tabs, indices, offsets)
+    assert bad == 2
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), ref)
+    before = [w.clone() for w in mod.split_embedding_weights()]
+    out.backward(torch.ones_like(out))
+    torch.cuda.synchronize()
+    oracle.tbe_backward(tabs, indices, offsets, np.ones(tuple(out.shape), np.float32), 0, 0.01)
+    for t, w in enumerate(mod.split_embedding_weights()):
+        np.testing.assert_allclose(w.cpu().numpy(), tabs.weights[t], rtol=2e-5, atol=2e-5)
+    assert mod.bounds_check_errors() == 4  # 2 in forward + 2 in backward
+    del before
+
+
+def test_empty_batch_and_empty_bags():
+    rows, dims = [10], [16]
+    mod, tabs = build_pair(rows, dims, None, 0)
+    out = mod(torch.zeros(0, dtype=torch.int64, device="cuda"), torch.zeros(5, dtype=torch.int64, device="cuda"))
+    assert out.shape == (4, 16) and float(out.abs().sum()) == 0.0
+    out.backward(torch.ones_like(out))  # N == 0: no-op
+    torch.cuda.synchronize()
+
+
+def test_full_size_criteo_shape_properties():
+    """BASELINE-size properties that need no oracle run: forward is a pure gather at L = 1
+    (every output block equals the addressed row), and SGD backward with unit grads moves each
+    touched row by -lr * multiplicity."""
+    B = 16384
+    rows = [45833188 // 64, 36746, 17245, 7413, 3, 62, 10, 4]  # Criteo mix, big table scaled to fit quickly
+    dims = [128] * len(rows)
+    rng = np.random.default_rng(0)
+    from fbgemm_gpu.split_table_batched_embeddings_ops import (
+        ComputeDevice, EmbeddingLocation, SplitTableBatchedEmbeddingBagsCodegen)
+    mod = SplitTableBatchedEmbeddingBagsCodegen(
+        [(r, d, EmbeddingLocation.DEVICE, ComputeDevice.CUDA) for r, d in zip(rows, dims)],
+        learning_rate=0.5, device=torch.device("cuda", 0))
+    for w in mod.split_embedding_weights():
+        w.uniform_(-1, 1)
+    indices, offsets, _ = make_inputs(rng, rows, B, 1, fixed_len=1)
+    idx_d, off_d = to_dev(indices), to_dev(offsets)
+    out = mod(idx_d, off_d)
+    ws = mod.split_embedding_weights()
+    for t in range(len(rows)):
+        expect = ws[t][idx_d[t * B:(t + 1) * B]]
+        assert torch.equal(out[:, t * 128:(t + 1) * 128], expect)
+    before = [w.clone() for w in ws]
+    out.backward(torch.ones_like(out))
+    torch.cuda.synchronize()
+    for t in range(len(rows)):
+        cnt = torch.bincount(idx_d[t * B:(t + 1) * B], minlength=rows[t]).float()
+        expect = before[t] - 0.5 * cnt[:, None]
+        torch.testing.assert_close(ws[t], expect, rtol=1e-5, atol=1e-3)
