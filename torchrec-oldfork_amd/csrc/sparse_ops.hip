@@ -339,6 +339,7 @@ extern "C" int tbe_cumsum(const void* in, void* out, int64_t n, int32_t elem_siz
   TBE_REQUIRE(n >= 0, "tbe_cumsum: n < 0");
   TBE_REQUIRE(elem_size == 4 || elem_size == 8, "tbe_cumsum: elem_size %d", elem_size);
   TBE_REQUIRE(mode >= 0 && mode <= 2, "tbe_cumsum: mode %d", mode);
+  if (n == 0 && mode != 0) return TBE_OK;  // nothing to write
   TBE_REQUIRE(out != nullptr && (n == 0 || in != nullptr), "tbe_cumsum: null pointer");
   if (n > kScanTile) {
     TBE_REQUIRE(workspace != nullptr && workspace_bytes >= scan_ws_bytes(n), "tbe_cumsum: workspace too small");
