@@ -76,21 +76,25 @@ int32_t tbe_abi_version(void);
  * DenseTableBatchedEmbeddingBagsCodegen.__call__ as called at
  * torchrec/distributed/batched_embedding_kernel.py:546-554.
  *
- *   out[b, feat_D_offset[f] + d] = sum_{i in bag(f,b)} w_i * W_f[indices[i], d]
+ *   out[b * out_row_stride + feat_out_offset[f] + d] = sum_{i in bag(f,b)} w_i * W_f[indices[i], d]
  *   (w_i = per_sample_weights[i] or 1; MEAN divides by the bag length)
  *
  * feat_weights   [F] device array of table base addresses (const float*), one per feature
  * feat_D         [F] embedding dim of the feature's table
- * feat_D_offset  [F+1] column offset of the feature in the pooled output (prefix sum of feat_D)
+ * feat_out_offset [F] int64 element offset of the feature's block for sample 0.  The reference layout
+ *                [B, sum D] is offset = prefix sum of feat_D, stride = sum D; an all-to-all-ready
+ *                layout [dst rank][B_local][D_local] (removes the split+cat copies of
+ *                torchrec/distributed/comm_ops.py:555-561 / :418-428) is expressed by making each
+ *                (src rank, feature) pair a pseudo-feature with offset = rank*B_local*D_local + col.
  * feat_rows      [F] number of rows of the feature's table (bounds check)
  * indices [N] int64, offsets [F*B+1] int64, per_sample_weights [N] float or NULL
- * out [B, out_row_stride] float, out_row_stride >= total_D (in elements)
+ * out: float buffer addressed as above; out_row_stride in elements
  * bounds_errors  optional device int32 counter: incremented for every index outside
  *                [0, rows); such an index contributes a zero row (never dereferenced).
  * ---------------------------------------------------------------------------------- */
 int tbe_forward_pooled_f32(const uint64_t* feat_weights, const int32_t* feat_D,
-                           const int32_t* feat_D_offset, const int64_t* feat_rows, int32_t F,
-                           int32_t B, int32_t total_D, int32_t max_D, const int64_t* indices,
+                           const int64_t* feat_out_offset, const int64_t* feat_rows, int32_t F,
+                           int32_t B, int32_t max_D, const int64_t* indices,
                            int64_t N, const int64_t* offsets, const float* per_sample_weights,
                            int32_t pooling_mode, float* out, int64_t out_row_stride,
                            int32_t* bounds_errors, void* stream);
@@ -118,16 +122,17 @@ int tbe_forward_nobag_f32(const uint64_t* feat_weights, const int64_t* feat_rows
  *                    (rowwise Adagrad: float[rows] momentum1; ADAM: float[rows*D] m, v;
  *                    DENSE_GRAD: state0 = float[rows*D] dense gradient table). May be NULL
  *                    for SGD.
- * grad_out [B, grad_row_stride] float (pooled) or [N, D] (pooling_mode NONE).
+ * grad_out: same addressing as the forward output (feat_out_offset, grad_row_stride) when pooled,
+ *           or [N, D] rows (grad_row_stride = D) for pooling_mode NONE.
  * workspace: at least tbe_backward_workspace_bytes(N, F, B, max_D, key_bits) bytes.
  * ---------------------------------------------------------------------------------- */
 size_t tbe_backward_workspace_bytes(int64_t N, int32_t F, int32_t B, int32_t max_D,
                                     int32_t key_bits);
 
 int tbe_backward_fused_f32(const uint64_t* feat_weights, const int32_t* feat_D,
-                           const int32_t* feat_D_offset, const int64_t* feat_rows,
+                           const int64_t* feat_out_offset, const int64_t* feat_rows,
                            const int64_t* feat_row_base, const uint64_t* feat_state0,
-                           const uint64_t* feat_state1, int32_t F, int32_t B, int32_t total_D,
+                           const uint64_t* feat_state1, int32_t F, int32_t B,
                            int32_t max_D, int32_t key_bits, const int64_t* indices, int64_t N,
                            const int64_t* offsets, const float* per_sample_weights,
                            int32_t pooling_mode, const float* grad_out,

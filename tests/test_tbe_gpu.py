@@ -278,3 +278,28 @@ def test_full_size_criteo_shape_properties():
         cnt = torch.bincount(idx_d[t * B:(t + 1) * B], minlength=rows[t]).float()
         expect = before[t] - 0.5 * cnt[:, None]
         torch.testing.assert_close(ws[t], expect, rtol=1e-5, atol=1e-3)
+
+
+def test_a2a_ready_output_layout_matches_standard_layout():
+    """Features = (src rank w, local feature f) pairs; the a2a-ready layout [W][B_l][D_local] must
+    hold exactly the standard [B_l, W*D_local] output re-sliced, forward and backward."""
+    rng = np.random.default_rng(12)
+    rows, dims = [300, 5, 77], [128, 64, 32]
+    W, Bl = 4, 50
+    ftm = [0, 1, 2] * W
+    mod_a, tabs = build_pair(rows, dims, ftm, 0, rng=np.random.default_rng(1), learning_rate=0.1)
+    mod_b, _ = build_pair(rows, dims, ftm, 0, rng=np.random.default_rng(1), learning_rate=0.1)
+    mod_b.set_a2a_output_layout(W)
+    indices, offsets, psw = make_inputs(rng, rows, Bl, 3, ftm, weighted=True)
+    oa = mod_a(to_dev(indices), to_dev(offsets), to_dev(psw))          # [Bl, W*Dl]
+    ob = mod_b(to_dev(indices), to_dev(offsets), to_dev(psw))          # [W*Bl, Dl]
+    Dl = sum(dims)
+    assert ob.shape == (W * Bl, Dl)
+    expect = oa.view(Bl, W, Dl).permute(1, 0, 2).reshape(W * Bl, Dl)
+    assert torch.equal(ob, expect)
+    g = torch.from_numpy(rng.standard_normal((Bl, W * Dl)).astype(np.float32)).cuda()
+    oa.backward(g)
+    ob.backward(g.view(Bl, W, Dl).permute(1, 0, 2).reshape(W * Bl, Dl).contiguous())
+    torch.cuda.synchronize()
+    for wa, wb in zip(mod_a.split_embedding_weights(), mod_b.split_embedding_weights()):
+        assert torch.equal(wa, wb)

@@ -34,7 +34,7 @@ namespace tbe {
 struct BwdArgs {
   const uint64_t* feat_weights;
   const int32_t* feat_D;
-  const int32_t* feat_D_offset;
+  const int64_t* feat_out_offset;
   const int64_t* feat_rows;
   const int64_t* feat_row_base;
   const uint64_t* feat_state0;
@@ -58,7 +58,8 @@ struct BwdArgs {
   const uint64_t* payload_sorted;
   float* partial_first;  // [nchunks][max_D_pad]
   float* partial_last;   // [nchunks][max_D_pad]
-  int32_t* origin;       // [nchunks]
+  int32_t* origin_list;  // [nchunks] chunks whose last run continues (compacted, any order)
+  int32_t* origin_count; // [1]
   int32_t max_D_pad;
   int32_t* bounds_errors;
 };
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(256) void bwd_update_kernel(BwdArgs a) {
         w_k = w_k / static_cast<float>(len);
       }
       gptr_k = nobag ? a.grad_out + static_cast<int64_t>(pos_k) * a.grad_stride
-                     : a.grad_out + static_cast<int64_t>(b_k) * a.grad_stride + a.feat_D_offset[f_k];
+                     : a.grad_out + static_cast<int64_t>(b_k) * a.grad_stride + a.feat_out_offset[f_k];
       lrow_k = static_cast<int64_t>(key_k) - a.feat_row_base[f_k];
       wptr_k = reinterpret_cast<const float*>(a.feat_weights[f_k]) + lrow_k * D_k;
     }
@@ -411,61 +412,182 @@ __global__ __launch_bounds__(256) void bwd_update_kernel(BwdArgs a) {
         if (d < a.max_D_pad) st4(dst + d, acc[v]);
       }
     }
-    if (gl == 0) a.origin[chunk] = is_origin;
+    if (gl == 0 && is_origin) a.origin_list[atomicAdd(a.origin_count, 1)] = static_cast<int32_t>(chunk);
   }
 }
 
-// One group per chunk: chunks flagged `origin` own a run that crosses into later chunks.
+// Fix-up: every "origin" chunk owns a run that continues into the following chunks.  One wave
+// per origin: the wave gallops over the following chunk heads (64 per step) to find the chain
+// length, its NG groups sum contiguous halves of the chain's partial rows (4 loads in flight)
+// and the halves are combined through LDS in fixed order.  Chains longer than kLongChain
+// (rows of tiny tables that receive thousands of contributions) are summed by the whole
+// workgroup: 4*NG groups, LDS-staged partials, fixed combine order => bitwise reproducible.
+constexpr int kLongChain = 24;
+
+template <typename KeyT, int G, int NV>
+struct FixupRow {
+  int f;
+  int D;
+  int64_t lrow;
+  float* wrow;
+  bool vec;
+};
+
+template <int G, int NV>
+__device__ __forceinline__ void sum_partials(const float* __restrict__ base, int max_D_pad, int64_t first,
+                                             int begin, int end, int D, int gl, float4 (&acc)[NV]) {
+  constexpr int U = 4;
+  for (int j = begin; j < end; j += U) {
+    float4 x[U][NV];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float* pf = base + (first + j + u) * max_D_pad;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int d = (v * G + gl) * 4;
+        x[u][v] = (j + u < end && d < D) ? ld4(pf + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        acc[v].x += x[u][v].x;
+        acc[v].y += x[u][v].y;
+        acc[v].z += x[u][v].z;
+        acc[v].w += x[u][v].w;
+      }
+  }
+}
+
 template <typename KeyT, int G, int NV>
 __global__ __launch_bounds__(256) void bwd_fixup_kernel(BwdArgs a) {
   constexpr int NG = kWave / G;
+  constexpr int NGB = 4 * NG;
+  __shared__ float4 part[NGB][NV][G];
+  __shared__ int64_t long_chunk[4];
+  __shared__ int long_len[4];
+  __shared__ int n_long;
   const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
   const int g = lane / G;
   const int gl = lane % G;
+  const int q = wave * NG + g;  // group index inside the block
   const int64_t nchunks = (a.N + a.C - 1) / a.C;
-  const int64_t chunk = (static_cast<int64_t>(blockIdx.x) * (blockDim.x / kWave) + (threadIdx.x >> 6)) * NG + g;
-  if (chunk >= nchunks) return;  // no cross-lane ops below except group_sum inside apply_row
-  const bool is_origin = a.origin[chunk] != 0;
-  // group_sum uses xor-shuffles within the group only; groups diverge freely.
-  if (!is_origin) return;
   const KeyT* __restrict__ skey = static_cast<const KeyT*>(a.keys_sorted);
-  const int64_t last_i = (chunk + 1) * a.C - 1;  // an origin chunk is always full
-  const KeyT key_run = skey[last_i];
-  const uint64_t pay = a.payload_sorted[last_i];
-  const uint32_t bag = static_cast<uint32_t>(pay >> 32);
-  const int f = static_cast<int>(bag / static_cast<uint32_t>(a.B));
-  const int D = a.feat_D[f];
-  const int64_t lrow = static_cast<int64_t>(key_run) - a.feat_row_base[f];
-  float* wrow = reinterpret_cast<float*>(a.feat_weights[f]) + lrow * D;
-  const bool vec = ((D & 3) == 0) && ((reinterpret_cast<uintptr_t>(wrow) & 15) == 0);
+  const int count = *a.origin_count;
 
-  float4 acc[NV], w[NV];
-  const float* pl = a.partial_last + chunk * a.max_D_pad;
+  for (int base = blockIdx.x * 4; base < count; base += gridDim.x * 4) {  // block-uniform
+    if (threadIdx.x == 0) n_long = 0;
+    __syncthreads();
+    const int oi = base + wave;
+    if (oi < count) {  // wave-uniform
+      const int64_t chunk = a.origin_list[oi];
+      const KeyT key_run = skey[(chunk + 1) * a.C - 1];
+      int len = 0;
+      bool more = true;
+      while (more) {
+        const int64_t cc = chunk + 1 + len + lane;
+        const bool ok = cc < nchunks && skey[cc * a.C] == key_run;
+        const unsigned long long m = __ballot(ok);
+        const int lead = (m == ~0ull) ? 64 : __builtin_ctzll(~m);
+        len += lead;
+        more = lead == 64;
+      }
+      if (len > kLongChain) {
+        if (lane == 0) {
+          const int s = atomicAdd(&n_long, 1);
+          long_chunk[s] = chunk;
+          long_len[s] = len;
+        }
+      } else {
+        const uint64_t pay = a.payload_sorted[(chunk + 1) * a.C - 1];
+        const int f = static_cast<int>(static_cast<uint32_t>(pay >> 32) / static_cast<uint32_t>(a.B));
+        const int D = a.feat_D[f];
+        const int64_t lrow = static_cast<int64_t>(key_run) - a.feat_row_base[f];
+        float* wrow = reinterpret_cast<float*>(a.feat_weights[f]) + lrow * D;
+        const bool vec = ((D & 3) == 0) && ((reinterpret_cast<uintptr_t>(wrow) & 15) == 0);
+        float4 acc[NV];
 #pragma unroll
-  for (int v = 0; v < NV; ++v) {
-    const int d = (v * G + gl) * 4;
-    acc[v] = (d < D) ? ld4(pl + d) : make_float4(0.f, 0.f, 0.f, 0.f);
-    w[v] = (d < D) ? ldc(wrow, d, D, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  int64_t cc = chunk + 1;
-  while (cc < nchunks) {
-    const float* pf = a.partial_first + cc * a.max_D_pad;
+        for (int v = 0; v < NV; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int per = (len + NG - 1) / NG;
+        sum_partials<G, NV>(a.partial_first, a.max_D_pad, chunk + 1, min(len, g * per), min(len, (g + 1) * per), D, gl, acc);
+        if (NG > 1) {
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      const int d = (v * G + gl) * 4;
-      if (d < D) {
-        const float4 o = ld4(pf + d);
-        acc[v].x += o.x;
-        acc[v].y += o.y;
-        acc[v].z += o.z;
-        acc[v].w += o.w;
+          for (int v = 0; v < NV; ++v) part[q][v][gl] = acc[v];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        if (g == 0) {
+          float4 tot[NV], w[NV];
+          const float* pl = a.partial_last + chunk * a.max_D_pad;
+#pragma unroll
+          for (int v = 0; v < NV; ++v) {
+            const int d = (v * G + gl) * 4;
+            tot[v] = (d < D) ? ld4(pl + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+            w[v] = (d < D) ? ldc(wrow, d, D, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+#pragma unroll
+          for (int v = 0; v < NV; ++v) {
+            tot[v].x += acc[v].x;
+            tot[v].y += acc[v].y;
+            tot[v].z += acc[v].z;
+            tot[v].w += acc[v].w;
+            for (int og = 1; og < NG; ++og) {
+              const float4 o = part[wave * NG + og][v][gl];
+              tot[v].x += o.x;
+              tot[v].y += o.y;
+              tot[v].z += o.z;
+              tot[v].w += o.w;
+            }
+          }
+          apply_row<G, NV>(a, f, lrow, D, vec, gl, wrow, w, tot);
+        }
       }
     }
-    const int64_t nx = (cc + 1) * a.C;
-    if (nx >= a.N || skey[nx] != key_run) break;
-    ++cc;
+    __syncthreads();
+    const int nl = n_long;
+    for (int s = 0; s < nl; ++s) {  // block-uniform
+      const int64_t chunk = long_chunk[s];
+      const int len = long_len[s];
+      const KeyT key_run = skey[(chunk + 1) * a.C - 1];
+      const uint64_t pay = a.payload_sorted[(chunk + 1) * a.C - 1];
+      const int f = static_cast<int>(static_cast<uint32_t>(pay >> 32) / static_cast<uint32_t>(a.B));
+      const int D = a.feat_D[f];
+      const int64_t lrow = static_cast<int64_t>(key_run) - a.feat_row_base[f];
+      float* wrow = reinterpret_cast<float*>(a.feat_weights[f]) + lrow * D;
+      const bool vec = ((D & 3) == 0) && ((reinterpret_cast<uintptr_t>(wrow) & 15) == 0);
+      float4 acc[NV];
+#pragma unroll
+      for (int v = 0; v < NV; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int per = (len + NGB - 1) / NGB;
+      sum_partials<G, NV>(a.partial_first, a.max_D_pad, chunk + 1, min(len, q * per), min(len, (q + 1) * per), D, gl, acc);
+      __syncthreads();  // previous iteration's readers are done with `part`
+#pragma unroll
+      for (int v = 0; v < NV; ++v) part[q][v][gl] = acc[v];
+      __syncthreads();
+      if (q == 0) {
+        float4 tot[NV], w[NV];
+        const float* pl = a.partial_last + chunk * a.max_D_pad;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          const int d = (v * G + gl) * 4;
+          tot[v] = (d < D) ? ld4(pl + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+          w[v] = (d < D) ? ldc(wrow, d, D, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+          for (int oq = 0; oq < NGB; ++oq) {
+            const float4 o = part[oq][v][gl];
+            tot[v].x += o.x;
+            tot[v].y += o.y;
+            tot[v].z += o.z;
+            tot[v].w += o.w;
+          }
+        }
+        apply_row<G, NV>(a, f, lrow, D, vec, gl, wrow, w, tot);
+      }
+    }
+    __syncthreads();
   }
-  apply_row<G, NV>(a, f, lrow, D, vec, gl, wrow, w, acc);
 }
 
 static int pick_chunk(int64_t N) {
@@ -483,7 +605,8 @@ struct BwdWorkspace {
   uint64_t* pay_out;
   float* partial_first;
   float* partial_last;
-  int32_t* origin;
+  int32_t* origin_list;
+  int32_t* origin_count;
   void* sort_tmp;
   size_t sort_tmp_bytes;
   size_t total;
@@ -516,7 +639,8 @@ static int carve(void* ws, int64_t N, int32_t max_D, int32_t key_bits, BwdWorksp
   out->pay_out = c.take<uint64_t>(N);
   out->partial_first = c.take<float>(nchunks * max_D_pad);
   out->partial_last = c.take<float>(nchunks * max_D_pad);
-  out->origin = c.take<int32_t>(nchunks);
+  out->origin_list = c.take<int32_t>(nchunks);
+  out->origin_count = c.take<int32_t>(1);
   out->sort_tmp = c.take_bytes(sort_bytes);
   out->sort_tmp_bytes = sort_bytes;
   out->total = c.total();
@@ -531,7 +655,8 @@ static int launch_update(const BwdArgs& a, hipStream_t st) {
   const unsigned grid = static_cast<unsigned>((nchunks + groups_per_block - 1) / groups_per_block);
   hipLaunchKernelGGL((bwd_update_kernel<KeyT, G, NV>), dim3(grid), dim3(256), 0, st, a);
   TBE_CHECK_LAUNCH("tbe_backward update");
-  hipLaunchKernelGGL((bwd_fixup_kernel<KeyT, G, NV>), dim3(grid), dim3(256), 0, st, a);
+  const unsigned fgrid = static_cast<unsigned>(std::min<int64_t>((nchunks + 3) / 4, 1024));
+  hipLaunchKernelGGL((bwd_fixup_kernel<KeyT, G, NV>), dim3(fgrid), dim3(256), 0, st, a);
   TBE_CHECK_LAUNCH("tbe_backward fixup");
   return TBE_OK;
 }
@@ -554,6 +679,10 @@ static int run_backward(BwdArgs a, const BwdWorkspace& w, int32_t max_D, hipStre
                        a.bounds_errors);
   }
   TBE_CHECK_LAUNCH("tbe_backward linearize");
+  if (hipMemsetAsync(a.origin_count, 0, sizeof(int32_t), st) != hipSuccess) {
+    set_error("tbe_backward: hipMemsetAsync failed");
+    return TBE_ERR_LAUNCH;
+  }
   size_t tmp_bytes = w.sort_tmp_bytes;
   hipError_t e = sort_pairs<KeyT>(w.sort_tmp, tmp_bytes, kin, kout, w.pay_in, w.pay_out, a.N, a.key_bits, st);
   if (e != hipSuccess) {
@@ -585,9 +714,9 @@ extern "C" size_t tbe_backward_workspace_bytes(int64_t N, int32_t F, int32_t B, 
 }
 
 extern "C" int tbe_backward_fused_f32(
-    const uint64_t* feat_weights, const int32_t* feat_D, const int32_t* feat_D_offset,
+    const uint64_t* feat_weights, const int32_t* feat_D, const int64_t* feat_out_offset,
     const int64_t* feat_rows, const int64_t* feat_row_base, const uint64_t* feat_state0,
-    const uint64_t* feat_state1, int32_t F, int32_t B, int32_t total_D, int32_t max_D,
+    const uint64_t* feat_state1, int32_t F, int32_t B, int32_t max_D,
     int32_t key_bits, const int64_t* indices, int64_t N, const int64_t* offsets,
     const float* per_sample_weights, int32_t pooling_mode, const float* grad_out,
     int64_t grad_row_stride, tbe_optimizer_args opt, void* workspace, size_t workspace_bytes,
@@ -599,7 +728,7 @@ extern "C" int tbe_backward_fused_f32(
               "tbe_backward_fused_f32: pooling_mode %d", pooling_mode);
   TBE_REQUIRE(static_cast<int64_t>(F) * B < (1ll << 32) && N < (1ll << 32),
               "tbe_backward_fused_f32: F*B and N must be < 2^32");
-  if (pooling_mode != TBE_POOL_NONE) TBE_REQUIRE(grad_row_stride >= total_D, "tbe_backward_fused_f32: grad_row_stride < total_D");
+  TBE_REQUIRE(grad_row_stride > 0, "tbe_backward_fused_f32: grad_row_stride <= 0");
   switch (opt.optimizer) {
     case TBE_OPT_EXACT_SGD:
       break;
@@ -617,7 +746,7 @@ extern "C" int tbe_backward_fused_f32(
       return TBE_ERR_UNSUPPORTED;
   }
   if (N == 0 || B == 0) return TBE_OK;
-  TBE_REQUIRE(feat_weights && feat_D && feat_D_offset && feat_rows && feat_row_base && indices && offsets && grad_out && workspace,
+  TBE_REQUIRE(feat_weights && feat_D && feat_out_offset && feat_rows && feat_row_base && indices && offsets && grad_out && workspace,
               "tbe_backward_fused_f32: null pointer");
   TBE_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "tbe_backward_fused_f32: workspace must be 256-B aligned");
   BwdWorkspace w;
@@ -630,7 +759,7 @@ extern "C" int tbe_backward_fused_f32(
   BwdArgs a{};
   a.feat_weights = feat_weights;
   a.feat_D = feat_D;
-  a.feat_D_offset = feat_D_offset;
+  a.feat_out_offset = feat_out_offset;
   a.feat_rows = feat_rows;
   a.feat_row_base = feat_row_base;
   a.feat_state0 = feat_state0;
@@ -655,7 +784,8 @@ extern "C" int tbe_backward_fused_f32(
   }
   a.partial_first = w.partial_first;
   a.partial_last = w.partial_last;
-  a.origin = w.origin;
+  a.origin_list = w.origin_list;
+  a.origin_count = w.origin_count;
   a.max_D_pad = (max_D + 3) / 4 * 4;
   a.bounds_errors = bounds_errors;
   hipStream_t st = static_cast<hipStream_t>(stream);

@@ -25,7 +25,7 @@ namespace tbe {
 struct FwdArgs {
   const uint64_t* feat_weights;
   const int32_t* feat_D;
-  const int32_t* feat_D_offset;
+  const int64_t* feat_out_offset;
   const int64_t* feat_rows;
   const int64_t* indices;
   const int64_t* offsets;
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void tbe_fwd_short_kernel(FwdArgs a) {
 
   const float* __restrict__ W = reinterpret_cast<const float*>(a.feat_weights[f]);
   const int D = a.feat_D[f];
-  const int Doff = a.feat_D_offset[f];
+  const int64_t Doff = a.feat_out_offset[f];
   const int64_t rows = a.feat_rows[f];
   const bool vec = ((D & 3) == 0) && ((Doff & 3) == 0) && ((a.out_stride & 3) == 0) &&
                    ((reinterpret_cast<uintptr_t>(W) & 15) == 0) &&
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void tbe_fwd_long_kernel(FwdArgs a) {
   const int b = static_cast<int>(bag % a.B);
   const float* __restrict__ W = reinterpret_cast<const float*>(a.feat_weights[f]);
   const int D = a.feat_D[f];
-  const int Doff = a.feat_D_offset[f];
+  const int64_t Doff = a.feat_out_offset[f];
   const int64_t rows = a.feat_rows[f];
   const bool vec = ((D & 3) == 0) && ((Doff & 3) == 0) && ((a.out_stride & 3) == 0) &&
                    ((reinterpret_cast<uintptr_t>(W) & 15) == 0) &&
@@ -405,8 +405,8 @@ static int launch_fwd(const FwdArgs& a, bool weighted, bool mean, bool long_bags
 using namespace tbe;
 
 extern "C" int tbe_forward_pooled_f32(const uint64_t* feat_weights, const int32_t* feat_D,
-                                      const int32_t* feat_D_offset, const int64_t* feat_rows,
-                                      int32_t F, int32_t B, int32_t total_D, int32_t max_D,
+                                      const int64_t* feat_out_offset, const int64_t* feat_rows,
+                                      int32_t F, int32_t B, int32_t max_D,
                                       const int64_t* indices, int64_t N, const int64_t* offsets,
                                       const float* per_sample_weights, int32_t pooling_mode,
                                       float* out, int64_t out_row_stride, int32_t* bounds_errors,
@@ -416,13 +416,13 @@ extern "C" int tbe_forward_pooled_f32(const uint64_t* feat_weights, const int32_
   TBE_REQUIRE(pooling_mode == TBE_POOL_SUM || pooling_mode == TBE_POOL_MEAN,
               "tbe_forward_pooled_f32: pooling_mode %d is not pooled", pooling_mode);
   TBE_REQUIRE(max_D > 0 && max_D <= 2048, "tbe_forward_pooled_f32: max_D=%d outside (0, 2048]", max_D);
-  TBE_REQUIRE(out_row_stride >= total_D, "tbe_forward_pooled_f32: out_row_stride < total_D");
+  TBE_REQUIRE(out_row_stride > 0, "tbe_forward_pooled_f32: out_row_stride <= 0");
   if (B == 0) return TBE_OK;
-  TBE_REQUIRE(feat_weights && feat_D && feat_D_offset && feat_rows && offsets && out,
+  TBE_REQUIRE(feat_weights && feat_D && feat_out_offset && feat_rows && offsets && out,
               "tbe_forward_pooled_f32: null pointer");
   TBE_REQUIRE(N == 0 || indices != nullptr, "tbe_forward_pooled_f32: null indices");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  FwdArgs a{feat_weights, feat_D, feat_D_offset, feat_rows, indices, offsets, per_sample_weights,
+  FwdArgs a{feat_weights, feat_D, feat_out_offset, feat_rows, indices, offsets, per_sample_weights,
             out, bounds_errors, out_row_stride, F, B};
   const bool weighted = per_sample_weights != nullptr;
   const bool mean = pooling_mode == TBE_POOL_MEAN;

@@ -41,7 +41,7 @@ SIGNATURES = {
     "tbe_abi_version": (c_i32, []),
     "tbe_forward_pooled_f32": (
         ctypes.c_int,
-        [c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_i32, c_i32, c_void_p, c_i64,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p, c_i64,
          c_void_p, c_void_p, c_i32, c_void_p, c_i64, c_void_p, c_void_p],
     ),
     "tbe_forward_nobag_f32": (
@@ -52,7 +52,7 @@ SIGNATURES = {
     "tbe_backward_workspace_bytes": (c_size, [c_i64, c_i32, c_i32, c_i32, c_i32]),
     "tbe_backward_fused_f32": (
         ctypes.c_int,
-        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_i32,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32,
          c_i32, c_i32, c_void_p, c_i64, c_void_p, c_void_p, c_i32, c_void_p, c_i64, OptimizerArgs,
          c_void_p, c_size, c_void_p, c_void_p],
     ),

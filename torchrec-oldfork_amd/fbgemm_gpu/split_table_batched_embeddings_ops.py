@@ -108,7 +108,7 @@ class _Layout:
         self.key = None
         self.feat_weights = None
         self.feat_D = None
-        self.feat_D_offset = None
+        self.feat_out_offset = None
         self.feat_rows = None
         self.feat_row_base = None
         self.feat_state0 = None
@@ -235,7 +235,7 @@ class _TBEBase(nn.Module):
 
         lay.feat_weights = i64([wptr[t] for t in ftm])
         lay.feat_D = i32(self.feat_D)
-        lay.feat_D_offset = i32(self.D_offsets)
+        lay.feat_out_offset = i64(self.D_offsets[:-1])
         lay.feat_rows = i64([self.rows_per_table[t] for t in ftm])
         lay.feat_row_base = i64([self.row_base[t] for t in ftm])
         lay.feat_state0 = i64([s0[t] for t in ftm]) if s0 is not None else None
@@ -275,6 +275,33 @@ class _TBEBase(nn.Module):
                 raise RuntimeError("per_sample_weights must have one entry per index")
         return indices, offsets, per_sample_weights, B
 
+    # -- output layout --------------------------------------------------------------------
+    def set_a2a_output_layout(self, world_size: int) -> None:
+        """Pooled output (and the gradient read by backward) laid out all-to-all-ready:
+        the module's features are (src rank w, local feature f) pairs, w-major, each rank
+        contributing ``B`` samples; output is ``[world_size, B, D_local]`` flattened, so slab w
+        is exactly what rank w receives.  Replaces the reference's recat permute +
+        split/cat copies (dist_data.py:257-263, comm_ops.py:555-561, :418-428)."""
+        if world_size < 1 or self.F % world_size != 0:
+            raise ValueError("feature count must be a multiple of world_size")
+        self._a2a_world = world_size
+        self._a2a_cache = {}
+
+    def _pooled_layout(self, B: int):
+        """(feat_out_offset tensor, row_stride, out_shape) for batch size B."""
+        lay = self._get_layout()
+        W = getattr(self, "_a2a_world", 0)
+        if not W:
+            return lay.feat_out_offset, self.total_D, (B, self.total_D)
+        hit = self._a2a_cache.get(B)
+        if hit is None:
+            Fl = self.F // W
+            Dl = self.D_offsets[Fl]
+            offs = [w * B * Dl + self.D_offsets[f] for w in range(W) for f in range(Fl)]
+            hit = (torch.tensor(offs, dtype=torch.int64).to(self.current_device), Dl, (W * B, Dl))
+            self._a2a_cache[B] = hit
+        return hit
+
     def _forward_impl(self, indices, offsets, per_sample_weights, B: int) -> torch.Tensor:
         lay = self._get_layout()
         dev = self.current_device
@@ -291,13 +318,14 @@ class _TBEBase(nn.Module):
                     "tbe_forward_nobag_f32",
                 )
                 return out
-            out = torch.empty((B, self.total_D), dtype=torch.float32, device=dev)
+            out_off, stride, shape = self._pooled_layout(B)
+            out = torch.empty(shape, dtype=torch.float32, device=dev)
             check(
                 lib.tbe_forward_pooled_f32(ptr(lay.feat_weights), ptr(lay.feat_D),
-                                           ptr(lay.feat_D_offset), ptr(lay.feat_rows), self.F, B,
-                                           self.total_D, self.max_D, ptr(indices), N, ptr(offsets),
+                                           ptr(out_off), ptr(lay.feat_rows), self.F, B,
+                                           self.max_D, ptr(indices), N, ptr(offsets),
                                            ptr(per_sample_weights), int(self.pooling_mode), ptr(out),
-                                           self.total_D, ptr(self._errors()), stream_ptr(dev)),
+                                           stride, ptr(self._errors()), stream_ptr(dev)),
                 "tbe_forward_pooled_f32",
             )
         return out
@@ -313,7 +341,10 @@ class _TBEBase(nn.Module):
         grad_out = grad_out.contiguous()
         if grad_out.dtype != torch.float32:
             grad_out = grad_out.float()
-        stride = grad_out.shape[1]
+        if self.pooling_mode == PoolingMode.NONE:
+            out_off, stride = lay.feat_out_offset, grad_out.shape[1]
+        else:
+            out_off, stride, _ = self._pooled_layout(B)
         feat_state0 = state0_override if state0_override is not None else lay.feat_state0
         with torch.cuda.device(dev):
             nbytes = lib.tbe_backward_workspace_bytes(N, self.F, B, self.max_D, self.key_bits)
@@ -322,9 +353,9 @@ class _TBEBase(nn.Module):
             ws = workspace(nbytes, dev)
             check(
                 lib.tbe_backward_fused_f32(ptr(lay.feat_weights), ptr(lay.feat_D),
-                                           ptr(lay.feat_D_offset), ptr(lay.feat_rows),
+                                           ptr(out_off), ptr(lay.feat_rows),
                                            ptr(lay.feat_row_base), ptr(feat_state0),
-                                           ptr(lay.feat_state1), self.F, B, self.total_D,
+                                           ptr(lay.feat_state1), self.F, B,
                                            self.max_D, self.key_bits, ptr(indices), N, ptr(offsets),
                                            ptr(per_sample_weights), int(self.pooling_mode),
                                            ptr(grad_out), stride, opt, ptr(ws), ws.numel(),
