@@ -1,0 +1,198 @@
+"""bench.py — samples/s of a DLRM training step on Criteo-1TB-shaped synthetic input, 1..8 MI355X.
+
+Metric (BASELINE.json): samples/sec, Criteo-1TB DLRM, global batch 65 536, at 1/2/4/8 GPUs, plus
+the fraction of the HBM roofline reached by the dominant embedding kernel, plus the reference's
+CPU EmbeddingBagCollection timed on this box's host cores.
+
+One "step" = one full training pass over one global batch: TBE forward (HIP), pooled exchange
+(RCCL all-to-all when N > 1), dense MLPs + dot interaction + BCE loss (fp32, rocBLAS/hipBLASLt),
+backward, TBE backward with the fused exact-SGD update (HIP), dense SGD step.  Inputs are
+resident in HBM when the timed region starts.  Scaling is STRONG: the global batch stays
+65 536 and is split over the ranks, as in the reference's published 8-GPU run
+(examples/dlrm/README.MD:38-45).
+
+Launch: `python bench.py --gpus 1 ...` or, for N > 1,
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+   --master-port P bench.py --gpus N --steps K --warmup W`.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import _paths  # noqa: E402,F401
+
+from fbgemm_gpu import _lib  # noqa: E402
+from torchrec_amd.datasets.random import (CRITEO_1TB_ROWS, DEFAULT_CAT_NAMES, INT_FEATURE_COUNT,  # noqa: E402
+                                          RandomRecDataset)
+from torchrec_amd.distributed.embeddingbag import EmbeddingBagCollectionSharder  # noqa: E402
+from torchrec_amd.distributed.model_parallel import DistributedModelParallel  # noqa: E402
+from torchrec_amd.distributed.train_pipeline import TrainPipelineSparseDist  # noqa: E402
+from torchrec_amd.distributed.types import ShardingEnv  # noqa: E402
+from torchrec_amd.models.dlrm import DLRMTrain  # noqa: E402
+from torchrec_amd.modules.embedding_configs import EmbeddingBagConfig  # noqa: E402
+from torchrec_amd.modules.embedding_modules import EmbeddingBagCollection  # noqa: E402
+from torchrec_amd.optim.keyed import CombinedOptimizer, KeyedOptimizerWrapper  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured copy rate
+D = 128
+F = len(CRITEO_1TB_ROWS)
+# SURVEY.md §8(d) algorithmic bytes per sample (fp32 rows, int64 indices/offsets, L = 1)
+BYTES_FWD = F * (D * 4 + 8) + F * 8 + F * D * 4          # 27 040
+BYTES_BWD_SGD = F * D * 4 + F * 16 + 2 * F * D * 4       # 40 352
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--global-batch", type=int, default=65536)
+    ap.add_argument("--lr", type=float, default=0.1)
+    ap.add_argument("--row-cap", type=int, default=0, help="debug: cap rows per table")
+    ap.add_argument("--zipf", type=float, default=0.0, help="Zipf alpha for ids (0 = uniform)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--num-batches", type=int, default=16, help="distinct pre-generated batches")
+    return ap.parse_args()
+
+
+def read_profile(lib, slot):
+    tot, n = ctypes.c_double(0.0), ctypes.c_int64(0)
+    lib.tbe_profile_read(slot, ctypes.byref(tot), ctypes.byref(n))
+    return tot.value, n.value
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+        env = ShardingEnv.from_process_group(dist.group.WORLD)
+    else:
+        env = ShardingEnv.from_local(1, 0)
+    if args.global_batch % world:
+        raise SystemExit("global batch must divide evenly over the ranks")
+    B_local = args.global_batch // world
+    rows = [min(r, args.row_cap) if args.row_cap else r for r in CRITEO_1TB_ROWS]
+
+    # ---- model: examples/dlrm/dlrm_main.py:498-540 ------------------------------------------------
+    tables = [EmbeddingBagConfig(name=f"t_{n}", embedding_dim=D, num_embeddings=rows[i], feature_names=[n])
+              for i, n in enumerate(DEFAULT_CAT_NAMES)]
+    ebc = EmbeddingBagCollection(tables=tables, device=torch.device("meta"))
+    train_model = DLRMTrain(embedding_bag_collection=ebc, dense_in_features=INT_FEATURE_COUNT,
+                            dense_arch_layer_sizes=[512, 256, 128],
+                            over_arch_layer_sizes=[1024, 1024, 512, 256, 1], dense_device=dev)
+    model = DistributedModelParallel(
+        module=train_model, env=env, device=dev,
+        sharders=[EmbeddingBagCollectionSharder(fused_params={"learning_rate": args.lr})])
+    dense_params = dict(model.named_parameters())
+    optimizer = CombinedOptimizer([
+        model.fused_optimizer,
+        KeyedOptimizerWrapper(dense_params, lambda p: torch.optim.SGD(p, lr=args.lr))])
+    plan = model.plan
+    n_rw = sum(1 for p in next(iter(plan.plan.values())).values() if p.sharding_type == "row_wise")
+
+    data = RandomRecDataset(DEFAULT_CAT_NAMES, B_local, rows, ids_per_feature=1, num_dense=INT_FEATURE_COUNT,
+                            manual_seed=1234 + rank, num_generated_batches=args.num_batches, device=dev,
+                            zipf_alpha=args.zipf or None)
+    it = iter(data)
+    pipe = TrainPipelineSparseDist(model, optimizer, dev)
+    model.train()
+    lib = _lib.load()
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        pipe.progress(it)
+    sync_all()
+    lib.tbe_profile_enable(1)
+    for s in range(3):
+        read_profile(lib, s)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pipe.progress(it)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    lib.tbe_profile_enable(0)
+    prof = [read_profile(lib, s) for s in range(3)]
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    value = args.global_batch * args.steps / elapsed
+
+    # ---- roofline of the dominant embedding kernel (this rank's launches) ---------------------------
+    # Units per launch on this rank: every TBE launch covers the GLOBAL batch for the features this
+    # rank holds (table-wise: whole features; row-wise: 1/W of a feature's rows => 1/W of its bytes).
+    shard = model.sharded_modules()[0]
+    feat_units = sum((1.0 / world) if shard._table_kind[i] < 0 else (1.0 if shard._table_kind[i] == rank else 0.0)
+                     for i in range(F))
+    per_feat_fwd = D * 4 + 8 + 8 + D * 4
+    per_feat_bwd = D * 4 + 16 + 2 * D * 4
+    kern = {}
+    for name, slot, per_feat in (("tbe_fwd_short_kernel", 0, per_feat_fwd), ("bwd_update_kernel", 1, per_feat_bwd),
+                                 ("tbe_backward_total", 2, per_feat_bwd)):
+        tot_ms, n = prof[slot]
+        if n:
+            avg_ms = tot_ms / n
+            kern[name] = {"avg_us": avg_ms * 1e3, "launches": n,
+                          "GB/s": feat_units * per_feat * args.global_batch / (avg_ms * 1e-3) / 1e9}
+    dom = max((k for k in kern if k != "tbe_backward_total"), key=lambda k: kern[k]["avg_us"], default=None)
+    roofline = None
+    if dom:
+        roofline = {"kernel": dom, "bound": "hbm", "achieved": round(kern[dom]["GB/s"], 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(kern[dom]["GB/s"] / HBM_PEAK_GBS, 4), "traffic": None,
+                    "avg_launch_us": round(kern[dom]["avg_us"], 1),
+                    "all": {k: {kk: round(vv, 1) for kk, vv in v.items()} for k, v in kern.items()}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.ebc_torch import time_cpu_baseline
+
+        r = time_cpu_baseline(CRITEO_1TB_ROWS, D, batch=4096, seconds_budget=args.cpu_seconds)
+        cpu = {"value": round(r["train_samples_per_s"], 1), "unit": "samples/s", "cores": r["cores"], "kind": "port",
+               "fwd_only_value": round(r["fwd_samples_per_s"], 1),
+               "sample": (f"reference EmbeddingBagCollection design (26 x nn.EmbeddingBag sum, sparse=True + SGD; "
+                          f"embedding part only, no MLPs) batch {r['batch']}, tables capped at {r['row_cap']} rows, "
+                          f"{r['train_iters']} train + {r['fwd_iters']} fwd iterations")}
+
+    if rank == 0:
+        out = {
+            "metric": "samples/sec Criteo-1TB DLRM batch 65536", "value": round(value, 1), "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "DLRM Criteo-1TB shape: 26 tables (177.9M rows, 84.85 GiB fp32, D=128), 13 dense, "
+                                   "pooling factor 1, dense 512-256-128, over 1024-1024-512-256-1, fused exact SGD",
+                       "global_batch": args.global_batch, "local_batch": B_local,
+                       "parallelism": f"mp{world}: {F - n_rw} table-wise + {n_rw} row-wise tables, dense dp{world}",
+                       "ids": f"zipf({args.zipf})" if args.zipf else "uniform", "row_cap": args.row_cap or None},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

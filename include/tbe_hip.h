@@ -71,6 +71,17 @@ typedef struct tbe_optimizer_args {
 const char* tbe_last_error(void);
 int32_t tbe_abi_version(void);
 
+/* Optional kernel timing for the measurement harness (bench.py `roofline`): when enabled the
+ * library brackets its dominant kernels with HIP events recorded on the launch stream.
+ * tbe_profile_read(slot) synchronises on the recorded events, returns the summed duration and
+ * launch count since the last read, and clears the slot.  Never enabled by the product path. */
+#define TBE_PROFILE_FWD_KERNEL 0        /* tbe_fwd_*_kernel, one launch per forward call */
+#define TBE_PROFILE_BWD_UPDATE_KERNEL 1 /* bwd_update_kernel, one launch per backward call */
+#define TBE_PROFILE_BWD_TOTAL 2         /* whole backward: linearize + sort + update + fix-up */
+#define TBE_PROFILE_NUM_SLOTS 3
+int tbe_profile_enable(int32_t on);
+int tbe_profile_read(int32_t slot, double* total_ms, int64_t* count);
+
 /* ------------------------------------------------------------------------------------
  * TBE forward (pooled): replaces SplitTableBatchedEmbeddingBagsCodegen.__call__ /
  * DenseTableBatchedEmbeddingBagsCodegen.__call__ as called at
@@ -210,6 +221,32 @@ int tbe_a2a_pooled_unpack(const float* recv, float* out, const int32_t* dim_sum_
 int tbe_a2a_pooled_pack(const float* grad, float* send, const int32_t* dim_sum_per_rank,
                         int32_t W, int32_t B_local, int32_t D_total,
                         int32_t dims_multiple_of_4, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Mixed table-wise + row-wise pooled exchange through ONE all-to-all (xGMI is point-to-point:
+ * an all-to-all drives all 7 links, a ring reduce-scatter is bound by one).  Replaces, on the
+ * receiver, All2All_Pooled_Wait's split+cat (torchrec/distributed/comm_ops.py:555-561), the
+ * reduce_scatter of row-wise partial pools (comm_ops.py:848-930) and the cross-sharding-type
+ * torch.cat (torchrec/distributed/embeddingbag.py:212-223); `pack` is the gradient transpose
+ * (comm_ops.py:418-428 recat + :922-927 all_gather), with the 1/W division fused as `scale`.
+ *   exchange buffer: W slabs, slab r = [B_local][slab_stride[r]] at element slab_offset[r]
+ *   matrix:          [B_local, D_total], global feature g occupies columns
+ *                    [feat_out_col[g], feat_out_col[g+1])
+ *   feat_src[g] >= 0 : table-wise, lives in slab feat_src[g] at column feat_slab_col[g]
+ *   feat_src[g] <  0 : row-wise, every slab holds a partial pool at column feat_slab_col[g];
+ *                      unpack sums them in rank order 0..W-1, pack broadcasts the gradient.
+ * all_multiple_of_4 != 0 asserts every column offset / dim / stride is a multiple of 4.
+ * ---------------------------------------------------------------------------------- */
+int tbe_pooled_exchange_unpack(const float* recv, float* out, const int32_t* feat_out_col,
+                               const int32_t* feat_src, const int32_t* feat_slab_col,
+                               const int64_t* slab_offset, const int32_t* slab_stride,
+                               int32_t Fg, int32_t W, int32_t B_local, int32_t D_total,
+                               int32_t all_multiple_of_4, float scale, void* stream);
+int tbe_pooled_exchange_pack(const float* grad, float* send, const int32_t* feat_out_col,
+                             const int32_t* feat_src, const int32_t* feat_slab_col,
+                             const int64_t* slab_offset, const int32_t* slab_stride,
+                             int32_t Fg, int32_t W, int32_t B_local, int32_t D_total,
+                             int32_t all_multiple_of_4, float scale, void* stream);
 
 /* torch.ops.fbgemm.jagged_2d_to_dense (examples/bert4rec/models/bert4rec.py:394-400):
  * values [N, D] + offsets [B+1] -> dense [B, max_L, D], zero padded / truncated. */

@@ -1,0 +1,70 @@
+"""CPU baseline = the reference's unsharded design, restated: a dict of
+``torch.nn.EmbeddingBag(mode="sum", include_last_offset=True)`` looped per table / feature and
+``torch.cat(dim=1)`` (torchrec/modules/embedding_modules.py:149-156, 174-193), plus the
+``sparse=True`` bags + ``torch.optim.SGD`` the reference's `sparse` compute kernel uses for
+training (torchrec/distributed/embedding_kernel.py:221-257).
+
+TEST INFRASTRUCTURE / cpu_baseline only (never imported by the product).  Equivalence with the
+reference module itself is pinned by tests/test_oracle_golden.py::test_ebc_torch_matches_golden.
+"""
+import time
+from typing import List, Optional
+
+import torch
+from torch import nn
+
+
+class RefEmbeddingBagCollection(nn.Module):
+    def __init__(self, rows: List[int], dims: List[int], pooling: str = "sum", sparse: bool = False) -> None:
+        super().__init__()
+        self.embedding_bags = nn.ModuleDict({
+            f"t{i}": nn.EmbeddingBag(num_embeddings=r, embedding_dim=d, mode=pooling, include_last_offset=True,
+                                     sparse=sparse)
+            for i, (r, d) in enumerate(zip(rows, dims))})
+        self.F = len(rows)
+
+    def forward(self, values: torch.Tensor, offsets: torch.Tensor, weights: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """values/offsets: feature-major KJT arrays (offsets has F*B+1 entries)."""
+        B = (offsets.numel() - 1) // self.F
+        pooled = []
+        for f in range(self.F):
+            o = offsets[f * B:(f + 1) * B + 1]
+            s, e = int(o[0]), int(o[-1])
+            pooled.append(self.embedding_bags[f"t{f}"](
+                input=values[s:e], offsets=o - o[0],
+                per_sample_weights=weights[s:e] if weights is not None else None))
+        return torch.cat(pooled, dim=1)
+
+
+def time_cpu_baseline(rows: List[int], dim: int, batch: int, seconds_budget: float = 20.0, row_cap: int = 1 << 20,
+                      seed: int = 1234):
+    """Times forward and forward+backward+SGD of the reference design on the host cores with the
+    same id distribution as the GPU run (uniform, pooling factor 1).  Tables are capped at
+    `row_cap` rows so that initialisation stays bounded; returns a dict for bench.py."""
+    g = torch.Generator()
+    g.manual_seed(seed)
+    capped = [min(r, row_cap) for r in rows]
+    F = len(rows)
+    ebc = RefEmbeddingBagCollection(capped, [dim] * F, sparse=True)
+    values = torch.cat([torch.randint(0, r, (batch,), generator=g) for r in capped])
+    offsets = torch.arange(F * batch + 1)
+    opt = torch.optim.SGD(ebc.parameters(), lr=0.01)
+    ebc(values, offsets)  # warm-up
+    t0, n_f = time.perf_counter(), 0
+    with torch.no_grad():
+        while time.perf_counter() - t0 < seconds_budget / 3 or n_f < 2:
+            ebc(values, offsets)
+            n_f += 1
+    fwd_s = (time.perf_counter() - t0) / n_f
+    grad = torch.randn(batch, F * dim, generator=g)
+    t0, n_t = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds_budget * 2 / 3 or n_t < 2:
+        opt.zero_grad()
+        ebc(values, offsets).backward(grad)
+        opt.step()
+        n_t += 1
+    train_s = (time.perf_counter() - t0) / n_t
+    return {
+        "fwd_samples_per_s": batch / fwd_s, "train_samples_per_s": batch / train_s,
+        "cores": torch.get_num_threads(), "batch": batch, "row_cap": row_cap, "fwd_iters": n_f, "train_iters": n_t,
+    }

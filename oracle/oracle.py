@@ -197,3 +197,24 @@ def offsets_range(offsets, range_size: int) -> np.ndarray:
     out = np.zeros(range_size, dtype=np.int64)
     lib().oracle_offsets_range(_p(offsets), ctypes.c_int64(offsets.size), ctypes.c_int64(range_size), _p(out))
     return out
+
+
+def pooled_exchange(buf_or_mat, feat_out_col, feat_src, feat_slab_col, slab_offset, slab_stride, B_local: int,
+                    pack: bool, scale: float = 1.0, buf_numel: int = 0) -> np.ndarray:
+    """unpack: buf [exchange buffer] -> [B_local, D_total]; pack: matrix -> exchange buffer."""
+    col = _c(feat_out_col, np.int32)
+    src = _c(feat_src, np.int32)
+    scol = _c(feat_slab_col, np.int32)
+    soff = _c(slab_offset, np.int64)
+    sstr = _c(slab_stride, np.int32)
+    Fg, W, D_total = src.size, soff.size, int(col[-1])
+    x = _c(buf_or_mat, np.float32)
+    if pack:
+        out = np.zeros(buf_numel, dtype=np.float32)
+        lib().oracle_pooled_exchange_pack(_p(x), _p(out), _p(col), _p(src), _p(scol), _p(soff), _p(sstr), Fg, W,
+                                          B_local, D_total, ctypes.c_float(scale))
+    else:
+        out = np.zeros((B_local, D_total), dtype=np.float32)
+        lib().oracle_pooled_exchange_unpack(_p(x), _p(out), _p(col), _p(src), _p(scol), _p(soff), _p(sstr), Fg, W,
+                                            B_local, D_total, ctypes.c_float(scale))
+    return out

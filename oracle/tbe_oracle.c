@@ -344,3 +344,43 @@ void oracle_offsets_range(const int64_t* offsets, int64_t n, int64_t range_size,
     out[i] = i - offsets[k];
   }
 }
+
+/* Mixed table-wise + row-wise exchange (see include/tbe_hip.h tbe_pooled_exchange_*):
+ * restates All2All_Pooled_Wait split+cat (comm_ops.py:555-561) for table-wise features and the
+ * reduce_scatter sum (comm_ops.py:848-930) for row-wise features, summed in rank order. */
+void oracle_pooled_exchange_unpack(const float* recv, float* out, const int32_t* feat_out_col,
+                                   const int32_t* feat_src, const int32_t* feat_slab_col,
+                                   const int64_t* slab_offset, const int32_t* slab_stride, int32_t Fg,
+                                   int32_t W, int32_t B_local, int32_t D_total, float scale) {
+  for (int32_t b = 0; b < B_local; ++b)
+    for (int32_t g = 0; g < Fg; ++g)
+      for (int32_t c = feat_out_col[g]; c < feat_out_col[g + 1]; ++c) {
+        const int32_t within = feat_slab_col[g] + (c - feat_out_col[g]);
+        float v;
+        if (feat_src[g] >= 0) {
+          const int32_t r = feat_src[g];
+          v = recv[slab_offset[r] + (int64_t)b * slab_stride[r] + within];
+        } else {
+          v = recv[slab_offset[0] + (int64_t)b * slab_stride[0] + within];
+          for (int32_t r = 1; r < W; ++r) v += recv[slab_offset[r] + (int64_t)b * slab_stride[r] + within];
+        }
+        out[(int64_t)b * D_total + c] = v * scale;
+      }
+}
+void oracle_pooled_exchange_pack(const float* grad, float* send, const int32_t* feat_out_col,
+                                 const int32_t* feat_src, const int32_t* feat_slab_col,
+                                 const int64_t* slab_offset, const int32_t* slab_stride, int32_t Fg,
+                                 int32_t W, int32_t B_local, int32_t D_total, float scale) {
+  for (int32_t b = 0; b < B_local; ++b)
+    for (int32_t g = 0; g < Fg; ++g)
+      for (int32_t c = feat_out_col[g]; c < feat_out_col[g + 1]; ++c) {
+        const int32_t within = feat_slab_col[g] + (c - feat_out_col[g]);
+        const float v = grad[(int64_t)b * D_total + c] * scale;
+        if (feat_src[g] >= 0) {
+          const int32_t r = feat_src[g];
+          send[slab_offset[r] + (int64_t)b * slab_stride[r] + within] = v;
+        } else {
+          for (int32_t r = 0; r < W; ++r) send[slab_offset[r] + (int64_t)b * slab_stride[r] + within] = v;
+        }
+      }
+}

@@ -12,7 +12,10 @@ import _paths  # noqa: F401
 import fbgemm_gpu  # noqa: F401  (defines the op schemas)
 from oracle import oracle
 
+import torchrec_amd.distributed._device_ops  # noqa: F401,E402  (defines torch.ops.tbe_hip schemas)
+
 _lib = torch.library.Library("fbgemm", "IMPL", "CPU")
+_lib2 = torch.library.Library("tbe_hip", "IMPL", "CPU")
 _registered = False
 
 
@@ -45,6 +48,18 @@ def _jagged_2d_to_dense(values, offsets, max_sequence_length):
                                                       max_sequence_length))
 
 
+def _x_unpack(recv, feat_out_col, feat_src, feat_slab_col, slab_offset, slab_stride, B_local, D_total, vec, scale):
+    return torch.from_numpy(oracle.pooled_exchange(recv.numpy(), feat_out_col.numpy(), feat_src.numpy(),
+                                                   feat_slab_col.numpy(), slab_offset.numpy(), slab_stride.numpy(),
+                                                   B_local, False, scale))
+
+
+def _x_pack(grad, feat_out_col, feat_src, feat_slab_col, slab_offset, slab_stride, numel, vec, scale):
+    return torch.from_numpy(oracle.pooled_exchange(grad.contiguous().numpy(), feat_out_col.numpy(), feat_src.numpy(),
+                                                   feat_slab_col.numpy(), slab_offset.numpy(), slab_stride.numpy(),
+                                                   grad.shape[0], True, scale, numel))
+
+
 def register() -> None:
     global _registered
     if _registered:
@@ -56,4 +71,6 @@ def register() -> None:
     _lib.impl("block_bucketize_sparse_features", _bucketize)
     _lib.impl("offsets_range", _offsets_range)
     _lib.impl("jagged_2d_to_dense", _jagged_2d_to_dense)
+    _lib2.impl("pooled_exchange_unpack", _x_unpack)
+    _lib2.impl("pooled_exchange_pack", _x_pack)
     _registered = True

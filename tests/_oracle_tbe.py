@@ -1,0 +1,73 @@
+"""TEST-ONLY stand-in for SplitTableBatchedEmbeddingBagsCodegen that computes with the CPU oracle.
+Lets the world_size-2 gloo tests exercise the distributed host logic (input dist, pooled exchange,
+sharding bookkeeping) without a GPU.  Never imported by the product."""
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+from torch import nn
+
+import _paths  # noqa: F401
+from oracle import oracle
+
+
+class _Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, placeholder, mod, indices, offsets, psw):
+        ctx.mod = mod
+        ctx.save_for_backward(indices, offsets, psw)
+        out, _ = oracle.tbe_forward(mod.tables, indices.numpy(), offsets.numpy(),
+                                    psw.numpy() if psw is not None else None, mod.pooling)
+        return mod._to_layout(torch.from_numpy(out))
+
+    @staticmethod
+    def backward(ctx, grad):
+        indices, offsets, psw = ctx.saved_tensors
+        mod = ctx.mod
+        g = mod._from_layout(grad.contiguous())
+        oracle.tbe_backward(mod.tables, indices.numpy(), offsets.numpy(), g.numpy(), oracle.OPT_EXACT_SGD,
+                            mod.optimizer_args.learning_rate, psw.numpy() if psw is not None else None, mod.pooling)
+        return None, None, None, None, None
+
+
+class OracleTBE(nn.Module):
+    def __init__(self, specs, ftm, pooling_mode, device, fused_params):
+        super().__init__()
+        rows, dims = [s[0] for s in specs], [s[1] for s in specs]
+        self.tables = oracle.Tables(rows, dims, ftm)
+        self.pooling = int(pooling_mode)
+        self.F = len(ftm)
+        self.optimizer_args = SimpleNamespace(learning_rate=fused_params.get("learning_rate", 0.01))
+        self._W = 0
+        self.placeholder = nn.Parameter(torch.zeros(0))
+
+    def set_a2a_output_layout(self, W):
+        self._W = W
+
+    def _to_layout(self, out):  # [B, W*Dl] -> [W*B, Dl]
+        if not self._W:
+            return out
+        B = out.shape[0]
+        return out.view(B, self._W, -1).permute(1, 0, 2).reshape(self._W * B, -1).contiguous()
+
+    def _from_layout(self, g):
+        if not self._W:
+            return g
+        B = g.shape[0] // self._W
+        return g.view(self._W, B, -1).permute(1, 0, 2).reshape(B, -1).contiguous()
+
+    def split_embedding_weights(self):
+        return [torch.from_numpy(w) for w in self.tables.weights]
+
+    def split_optimizer_states(self):
+        return [() for _ in self.tables.weights]
+
+    def set_learning_rate(self, lr):
+        self.optimizer_args.learning_rate = lr
+
+    def forward(self, indices, offsets, psw=None):
+        return _Fn.apply(self.placeholder, self, indices.long(), offsets.long(), psw)
+
+
+def oracle_tbe_factory(specs, ftm, pooling_mode, device, fused_params):
+    return OracleTBE(specs, ftm, pooling_mode, device, fused_params)

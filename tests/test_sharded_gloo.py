@@ -1,0 +1,157 @@
+"""CPU, world_size 2 (gloo): the distributed host logic of the N > 1 path — planner, id input
+dist, a2a-ready TBE layout, ONE pooled all-to-all with table-wise copy + row-wise reduce, gradient
+exchange with 1/W division — against the unsharded oracle.  Follows the reference's core test
+pattern (sharded-vs-unsharded equivalence after one train step,
+torchrec/distributed/test_utils/test_model_parallel_base.py:148-294); compute is the oracle's
+(tests/_oracle_tbe.py) because the product has no CPU kernels."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import _paths  # noqa: F401
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+ROWS = [40, 7, 23, 90, 5]
+DIMS = [8, 8, 8, 8, 8]
+LR = 0.25
+
+
+def _global_data(W, B_local, fixed_len, weighted, seed=3):
+    rng = np.random.default_rng(seed)
+    F = len(ROWS)
+    per_rank = []
+    for r in range(W):
+        lengths = (np.full(F * B_local, fixed_len) if fixed_len else rng.integers(0, 4, size=F * B_local)).astype(np.int32)
+        vals = np.concatenate([rng.integers(0, ROWS[f], size=int(lengths[f * B_local:(f + 1) * B_local].sum()))
+                               for f in range(F)]).astype(np.int64)
+        wts = (rng.random(vals.size).astype(np.float32) + 0.5) if weighted else None
+        grad = rng.standard_normal((B_local, sum(DIMS))).astype(np.float32)
+        per_rank.append((lengths, vals, wts, grad))
+    init = [rng.standard_normal((r, d)).astype(np.float32) for r, d in zip(ROWS, DIMS)]
+    return per_rank, init
+
+
+def _worker(rank, W, port, fixed_len, weighted, n_rw, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=W)
+    try:
+        import _cpu_ops
+        _cpu_ops.register()
+        from _oracle_tbe import oracle_tbe_factory
+        from torchrec_amd.distributed.embeddingbag import ShardedEmbeddingBagCollection
+        from torchrec_amd.distributed.planner import EmbeddingShardingPlanner, Topology
+        from torchrec_amd.distributed.types import ShardingEnv
+        from torchrec_amd.modules.embedding_configs import EmbeddingBagConfig
+        from torchrec_amd.modules.embedding_modules import EmbeddingBagCollection
+        from torchrec_amd.sparse.jagged_tensor import KeyedJaggedTensor
+
+        B_local = 6
+        per_rank, init = _global_data(W, B_local, fixed_len, weighted)
+        keys = [f"f{i}" for i in range(len(ROWS))]
+        tables = [EmbeddingBagConfig(name=f"t{i}", embedding_dim=DIMS[i], num_embeddings=ROWS[i], feature_names=[keys[i]])
+                  for i in range(len(ROWS))]
+        ebc = EmbeddingBagCollection(tables, is_weighted=weighted, device=torch.device("meta"))
+        plan = EmbeddingShardingPlanner(Topology(W, "cpu"), num_row_wise=n_rw).plan_tables(tables)
+        env = ShardingEnv.from_process_group(dist.group.WORLD)
+        sebc = ShardedEmbeddingBagCollection(ebc, plan, env, {"learning_rate": LR}, torch.device("cpu"),
+                                             tbe_factory=oracle_tbe_factory)
+        # load the global initial weights into the local shards
+        for name, (w, row0) in sebc.local_shards().items():
+            t = int(name[1:])
+            w.copy_(torch.from_numpy(init[t][row0:row0 + w.shape[0]]))
+        lengths, vals, wts, grad = per_rank[rank]
+        if fixed_len:
+            kjt = KeyedJaggedTensor.from_fixed_lengths(keys, torch.from_numpy(vals), [fixed_len] * len(keys),
+                                                       weights=torch.from_numpy(wts) if weighted else None)
+        else:
+            kjt = KeyedJaggedTensor.from_lengths_sync(keys, torch.from_numpy(vals), torch.from_numpy(lengths),
+                                                      weights=torch.from_numpy(wts) if weighted else None)
+        out = sebc(kjt).wait()
+        assert out.keys() == keys
+        vals_out = out.values()
+        vals_out.backward(torch.from_numpy(grad))
+        shards = {n: (w.clone().numpy(), r0) for n, (w, r0) in sebc.local_shards().items()}
+        ret[rank] = (vals_out.detach().numpy().copy(), shards, {n: p.sharding_type for n, p in plan.items()})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fixed_len,weighted,n_rw", [(1, False, 1), (2, True, 2), (0, False, 1), (0, True, 0), (1, False, 5)])
+def test_sharded_equals_unsharded_world2(fixed_len, weighted, n_rw):
+    from oracle import oracle
+
+    W = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(W, _free_port(), fixed_len, weighted, n_rw, ret), nprocs=W, join=True)
+    per_rank, init = _global_data(W, 6, fixed_len, weighted)
+    # unsharded oracle on each rank's batch (forward), then ONE backward over the global batch with
+    # grads / W (GRADIENT_DIVISION, comm_ops.py:527-528)
+    tabs = oracle.Tables(ROWS, DIMS)
+    for t in range(len(ROWS)):
+        tabs.weights[t][...] = init[t]
+    F = len(ROWS)
+    for r in range(W):
+        lengths, vals, wts, grad = per_rank[r]
+        offs = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+        ref, _ = oracle.tbe_forward(tabs, vals, offs, wts)
+        np.testing.assert_allclose(ret[r][0], ref, rtol=1e-5, atol=1e-5)
+    kinds = ret[0][2]
+    assert sum(1 for k in kinds.values() if k == "row_wise") == n_rw
+    # global batch = rank-major concatenation per feature
+    B = 6
+    g_len = np.concatenate([np.concatenate([per_rank[r][0][f * B:(f + 1) * B] for r in range(W)]) for f in range(F)])
+    pos = [np.concatenate([[0], np.cumsum(per_rank[r][0])]) for r in range(W)]
+    g_vals = np.concatenate([np.concatenate([per_rank[r][1][pos[r][f * B]:pos[r][(f + 1) * B]] for r in range(W)]) for f in range(F)])
+    g_w = (np.concatenate([np.concatenate([per_rank[r][2][pos[r][f * B]:pos[r][(f + 1) * B]] for r in range(W)]) for f in range(F)])
+           if weighted else None)
+    g_grad = np.concatenate([per_rank[r][3] for r in range(W)], axis=0) / W
+    g_offs = np.concatenate([[0], np.cumsum(g_len)]).astype(np.int64)
+    oracle.tbe_backward(tabs, g_vals, g_offs, g_grad, oracle.OPT_EXACT_SGD, LR, g_w)
+    seen_rows = {t: 0 for t in range(F)}
+    for r in range(W):
+        for name, (w, row0) in ret[r][1].items():
+            t = int(name[1:])
+            np.testing.assert_allclose(w, tabs.weights[t][row0:row0 + w.shape[0]], rtol=1e-5, atol=1e-5)
+            seen_rows[t] += w.shape[0]
+    assert all(seen_rows[t] == ROWS[t] for t in range(F)), "every table row must live on exactly one rank"
+
+
+def test_planner_balances_criteo_over_8_ranks():
+    from torchrec_amd.datasets.random import CRITEO_1TB_ROWS
+    from torchrec_amd.distributed.planner import EmbeddingShardingPlanner, Topology, rw_shard_rows
+    from torchrec_amd.modules.embedding_configs import EmbeddingBagConfig
+
+    tables = [EmbeddingBagConfig(name=f"t{i}", embedding_dim=128, num_embeddings=r, feature_names=[f"c{i}"])
+              for i, r in enumerate(CRITEO_1TB_ROWS)]
+    for W in (1, 2, 4, 8):
+        plan = EmbeddingShardingPlanner(Topology(W)).plan_tables(tables)
+        rw = [n for n, p in plan.items() if p.sharding_type == "row_wise"]
+        assert len(rw) == (26 % W if W > 1 else 0)
+        per_rank = [sum(1 for p in plan.values() if p.sharding_type == "table_wise" and p.ranks == [r]) for r in range(W)]
+        assert max(per_rank) - min(per_rank) == 0, per_rank  # identical lookup volume on every rank
+        mem = [0] * W
+        for t in tables:
+            p = plan[t.name]
+            if p.sharding_type == "row_wise":
+                for r, n in enumerate(rw_shard_rows(t.num_embeddings, W)):
+                    mem[r] += n * 512
+            else:
+                mem[p.ranks[0]] += t.num_embeddings * 512
+        assert max(mem) < 288e9 * 0.85
+    # rw_shard_rows examples of planner/enumerators.py:277-312
+    assert rw_shard_rows(10, 3) == [4, 4, 2] and rw_shard_rows(5, 4) == [2, 2, 1, 0]

@@ -32,6 +32,19 @@ void set_error(const char* fmt, ...);
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// profile.cpp: optional HIP-event bracketing of a launch (no-op unless tbe_profile_enable(1)).
+bool profile_enabled();
+void profile_begin(int slot, hipStream_t st, hipEvent_t* after);
+void profile_end(hipEvent_t after, hipStream_t st);
+struct ProfileSpan {
+  hipEvent_t after = nullptr;
+  hipStream_t st;
+  ProfileSpan(int slot, hipStream_t s) : st(s) {
+    if (profile_enabled()) profile_begin(slot, s, &after);
+  }
+  ~ProfileSpan() { profile_end(after, st); }
+};
+
 // Carves 256-byte aligned sub-buffers out of a caller workspace.
 struct Carver {
   char* base;

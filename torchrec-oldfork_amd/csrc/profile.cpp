@@ -1,0 +1,75 @@
+// Optional in-library kernel timing with HIP events recorded on the SAME stream the kernels are
+// launched on (bench.py's roofline leg; torch.cuda.Event only sees torch's current stream and
+// cannot bracket one kernel inside tbe_backward_fused_f32).  Off by default: when disabled no
+// event is created or recorded.
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <vector>
+
+#include "../../include/tbe_hip.h"
+
+namespace tbe {
+
+struct Span {
+  hipEvent_t a, b;
+};
+static std::mutex g_mu;
+static bool g_on = false;
+static std::vector<Span> g_spans[TBE_PROFILE_NUM_SLOTS];
+
+bool profile_enabled() { return g_on; }
+
+// Returns an event to record before the launch (and registers its partner, returned via *after).
+void profile_begin(int slot, hipStream_t st, hipEvent_t* after) {
+  *after = nullptr;
+  if (!g_on || slot < 0 || slot >= TBE_PROFILE_NUM_SLOTS) return;
+  Span s;
+  if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_spans[slot].size() >= 65536) {
+      (void)hipEventDestroy(s.a);
+      (void)hipEventDestroy(s.b);
+      return;
+    }
+    g_spans[slot].push_back(s);
+  }
+  (void)hipEventRecord(s.a, st);
+  *after = s.b;
+}
+
+void profile_end(hipEvent_t after, hipStream_t st) {
+  if (after != nullptr) (void)hipEventRecord(after, st);
+}
+
+}  // namespace tbe
+
+extern "C" int tbe_profile_enable(int32_t on) {
+  std::lock_guard<std::mutex> lk(tbe::g_mu);
+  tbe::g_on = on != 0;
+  return TBE_OK;
+}
+
+extern "C" int tbe_profile_read(int32_t slot, double* total_ms, int64_t* count) {
+  if (slot < 0 || slot >= TBE_PROFILE_NUM_SLOTS || !total_ms || !count) return TBE_ERR_INVALID_ARGUMENT;
+  std::vector<tbe::Span> spans;
+  {
+    std::lock_guard<std::mutex> lk(tbe::g_mu);
+    spans.swap(tbe::g_spans[slot]);
+  }
+  double tot = 0.0;
+  int64_t n = 0;
+  for (auto& s : spans) {
+    float ms = 0.f;
+    if (hipEventSynchronize(s.b) == hipSuccess && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+      tot += ms;
+      ++n;
+    }
+    (void)hipEventDestroy(s.a);
+    (void)hipEventDestroy(s.b);
+  }
+  *total_ms = tot;
+  *count = n;
+  return TBE_OK;
+}

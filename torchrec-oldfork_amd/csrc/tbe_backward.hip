@@ -653,7 +653,10 @@ static int launch_update(const BwdArgs& a, hipStream_t st) {
   const int64_t nchunks = (a.N + a.C - 1) / a.C;
   const int64_t groups_per_block = 4 * NG;
   const unsigned grid = static_cast<unsigned>((nchunks + groups_per_block - 1) / groups_per_block);
-  hipLaunchKernelGGL((bwd_update_kernel<KeyT, G, NV>), dim3(grid), dim3(256), 0, st, a);
+  {
+    ProfileSpan span(TBE_PROFILE_BWD_UPDATE_KERNEL, st);
+    hipLaunchKernelGGL((bwd_update_kernel<KeyT, G, NV>), dim3(grid), dim3(256), 0, st, a);
+  }
   TBE_CHECK_LAUNCH("tbe_backward update");
   const unsigned fgrid = static_cast<unsigned>(std::min<int64_t>((nchunks + 3) / 4, 1024));
   hipLaunchKernelGGL((bwd_fixup_kernel<KeyT, G, NV>), dim3(fgrid), dim3(256), 0, st, a);
@@ -663,6 +666,7 @@ static int launch_update(const BwdArgs& a, hipStream_t st) {
 
 template <typename KeyT>
 static int run_backward(BwdArgs a, const BwdWorkspace& w, int32_t max_D, hipStream_t st) {
+  ProfileSpan total_span(TBE_PROFILE_BWD_TOTAL, st);
   KeyT* kin = static_cast<KeyT*>(w.keys_in);
   KeyT* kout = static_cast<KeyT*>(w.keys_out);
   if (a.pooling_mode == TBE_POOL_NONE) {

@@ -377,6 +377,7 @@ __global__ __launch_bounds__(256) void tbe_fwd_nobag_kernel(const uint64_t* feat
 template <int G, int NV>
 static int launch_fwd(const FwdArgs& a, bool weighted, bool mean, bool long_bags,
                       hipStream_t st) {
+  ProfileSpan span(TBE_PROFILE_FWD_KERNEL, st);
   if (long_bags) {
     const int64_t nbags = static_cast<int64_t>(a.F) * a.B;
     const unsigned grid = static_cast<unsigned>((nbags + 3) / 4);

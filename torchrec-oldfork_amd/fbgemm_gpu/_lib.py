@@ -39,6 +39,8 @@ class OptimizerArgs(ctypes.Structure):
 SIGNATURES = {
     "tbe_last_error": (ctypes.c_char_p, []),
     "tbe_abi_version": (c_i32, []),
+    "tbe_profile_enable": (ctypes.c_int, [c_i32]),
+    "tbe_profile_read": (ctypes.c_int, [c_i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]),
     "tbe_forward_pooled_f32": (
         ctypes.c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p, c_i64,
@@ -79,6 +81,14 @@ SIGNATURES = {
         ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_i32, c_i32, c_float, c_void_p]),
     "tbe_a2a_pooled_pack": (
         ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_i32, c_i32, c_float, c_void_p]),
+    "tbe_pooled_exchange_unpack": (
+        ctypes.c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_i32,
+         c_i32, c_i32, c_float, c_void_p]),
+    "tbe_pooled_exchange_pack": (
+        ctypes.c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_i32,
+         c_i32, c_i32, c_float, c_void_p]),
     "tbe_jagged_2d_to_dense_f32": (
         ctypes.c_int, [c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p, c_void_p]),
     "tbe_offsets_range": (ctypes.c_int, [c_void_p, c_i64, c_i64, c_void_p, c_void_p]),

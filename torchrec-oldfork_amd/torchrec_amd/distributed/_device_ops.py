@@ -1,0 +1,43 @@
+"""Device ops of the distributed layer that are not part of the fbgemm surface, exposed as
+dispatcher ops (`torch.ops.tbe_hip.*`) over the C ABI (include/tbe_hip.h
+tbe_pooled_exchange_*).  Only the HIP key is registered here; CPU tensors raise."""
+import torch
+
+from fbgemm_gpu import _lib
+from fbgemm_gpu._lib import check, ptr, require_gpu, stream_ptr
+
+_def = torch.library.Library("tbe_hip", "DEF")
+_def.define("pooled_exchange_unpack(Tensor recv, Tensor feat_out_col, Tensor feat_src, Tensor feat_slab_col, "
+            "Tensor slab_offset, Tensor slab_stride, int B_local, int D_total, bool vec, float scale) -> Tensor")
+_def.define("pooled_exchange_pack(Tensor grad, Tensor feat_out_col, Tensor feat_src, Tensor feat_slab_col, "
+            "Tensor slab_offset, Tensor slab_stride, int numel, bool vec, float scale) -> Tensor")
+_impl = torch.library.Library("tbe_hip", "IMPL", "CUDA")
+
+
+def _unpack(recv, feat_out_col, feat_src, feat_slab_col, slab_offset, slab_stride, B_local, D_total, vec, scale):
+    dev = require_gpu(recv, feat_out_col, feat_src, feat_slab_col, slab_offset, slab_stride)
+    recv = recv.contiguous()
+    out = torch.empty((B_local, D_total), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().tbe_pooled_exchange_unpack(
+            ptr(recv), ptr(out), ptr(feat_out_col), ptr(feat_src), ptr(feat_slab_col), ptr(slab_offset),
+            ptr(slab_stride), feat_src.numel(), slab_offset.numel(), B_local, D_total, int(vec), scale,
+            stream_ptr(dev)), "tbe_pooled_exchange_unpack")
+    return out
+
+
+def _pack(grad, feat_out_col, feat_src, feat_slab_col, slab_offset, slab_stride, numel, vec, scale):
+    dev = require_gpu(grad, feat_out_col, feat_src, feat_slab_col, slab_offset, slab_stride)
+    grad = grad.contiguous()
+    B_local, D_total = grad.shape
+    send = torch.empty(numel, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().tbe_pooled_exchange_pack(
+            ptr(grad), ptr(send), ptr(feat_out_col), ptr(feat_src), ptr(feat_slab_col), ptr(slab_offset),
+            ptr(slab_stride), feat_src.numel(), slab_offset.numel(), B_local, D_total, int(vec), scale,
+            stream_ptr(dev)), "tbe_pooled_exchange_pack")
+    return send
+
+
+_impl.impl("pooled_exchange_unpack", _unpack)
+_impl.impl("pooled_exchange_pack", _pack)

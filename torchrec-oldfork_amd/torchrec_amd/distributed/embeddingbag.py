@@ -1,0 +1,475 @@
+"""ShardedEmbeddingBagCollection for MI355X: table-wise + row-wise sharding of an
+EmbeddingBagCollection over the ranks of one node.
+
+Interface follows torchrec/distributed/embeddingbag.py:226-486 (input_dist -> compute ->
+output_dist, `compute_and_output_dist`, `fused_optimizer`, KeyedTensor result) and
+EmbeddingBagCollectionSharder (:489-515).  The data path is re-designed for xGMI / HIP:
+
+  reference (per sharding TYPE, embeddingbag.py:331-402)      this build (once, for all types)
+  --------------------------------------------------------    ------------------------------------------
+  kjt.permute + split                                          one gather of ids into send order
+  RW: block_bucketize + 2-phase lengths/values a2a + D2H sync  ids of row-wise features go to every rank,
+  TW: 2-phase lengths/values a2a + D2H sync                    rows outside a rank's block are masked by the
+  recat permute_2D on the receiver                             kernel's bounds check; with host-known pooling
+                                                               factors every size is static: ONE a2a, no sync,
+                                                               no recat (TBE consumes [src][feature][sample])
+  one TBE per (type, group) + cat                              ONE TBE per rank (row-wise shards + table-wise
+                                                               tables), output written a2a-ready
+  TW: a2a + split/cat; RW: ring reduce-scatter; cat            ONE a2a, then tbe_pooled_exchange_unpack (copy
+                                                               TW columns, sum RW partials in rank order)
+  backward: recat copy + a2a / all-gather, grads / W           tbe_pooled_exchange_pack (x 1/W fused) + ONE a2a
+
+Forward issues the lookup and the a2a before the caller's dense work and waits afterwards
+(`forward()` returns an awaitable), so the exchange overlaps the bottom MLP; autograd replays
+the same overlap in reverse for the gradient exchange.
+"""
+from typing import Any, Callable, Dict, Iterator, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from ..modules.embedding_configs import EmbeddingBagConfig, pooling_type_to_pooling_mode
+from ..modules.embedding_modules import EmbeddingBagCollection
+from ..sparse.jagged_tensor import KeyedJaggedTensor, KeyedTensor
+from . import _device_ops  # noqa: F401  (registers torch.ops.tbe_hip.*)
+from .planner import rw_block_size, rw_shard_rows
+from .types import Awaitable, LazyAwaitable, NoWait, ParameterSharding, ShardingEnv, ShardingType
+
+GRADIENT_DIVISION = True  # torchrec/distributed/comm_ops.py:35-40
+
+
+def set_gradient_division(val: bool) -> None:
+    global GRADIENT_DIVISION
+    GRADIENT_DIVISION = val
+
+
+def _default_tbe_factory(specs, ftm, pooling_mode, device, fused_params):
+    from fbgemm_gpu.split_table_batched_embeddings_ops import (
+        ComputeDevice, EmbeddingLocation, SplitTableBatchedEmbeddingBagsCodegen)
+
+    return SplitTableBatchedEmbeddingBagsCodegen(
+        embedding_specs=[(r, d, EmbeddingLocation.DEVICE, ComputeDevice.CUDA) for r, d in specs],
+        feature_table_map=ftm, pooling_mode=pooling_mode, device=device, **fused_params)
+
+
+class _LocalTable:
+    def __init__(self, cfg: EmbeddingBagConfig, local_rows: int, row_offset: int, row_wise: bool) -> None:
+        self.cfg, self.local_rows, self.row_offset, self.row_wise = cfg, local_rows, row_offset, row_wise
+
+
+class SparseFeaturesDist:
+    """What input_dist hands to compute (embedding_types.py `SparseFeatures`, after the a2a):
+    ids in [src rank][local feature][sample] order + offsets for the local TBE."""
+
+    def __init__(self, values, offsets, weights, batch_size: int) -> None:
+        self.values, self.offsets, self.weights, self.batch_size = values, offsets, weights, batch_size
+
+    def record_stream(self, stream) -> None:
+        for t in (self.values, self.offsets, self.weights):
+            if t is not None and t.is_cuda:
+                t.record_stream(stream)
+
+
+class _InputDistAwaitable(LazyAwaitable):
+    def __init__(self, fn: Callable[[], SparseFeaturesDist]) -> None:
+        super().__init__()
+        self._fn = fn
+
+    def _wait_impl(self) -> SparseFeaturesDist:
+        return self._fn()
+
+
+class _ExchangeReq(torch.autograd.Function):
+    """Forward: start the pooled all-to-all (async).  Backward: wait for the gradient all-to-all
+    that `_ExchangeWait.backward` started.  (Req/Wait split as comm_ops.py:462-605.)"""
+
+    @staticmethod
+    def forward(ctx, emb, state):
+        ctx.state = state
+        state.start_forward(emb)
+        return state.recv_fwd
+
+    @staticmethod
+    def backward(ctx, _unused):
+        return ctx.state.finish_backward(), None
+
+
+class _ExchangeWait(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, recv, state):
+        ctx.state = state
+        return state.finish_forward()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ctx.state.start_backward(grad_out)
+        return ctx.state.dummy_grad(), None
+
+
+class _ExchangeState:
+    """One step's pooled exchange: buffers, split sizes and in-flight work handles."""
+
+    def __init__(self, owner: "ShardedEmbeddingBagCollection", B: int) -> None:
+        self.o, self.B = owner, B
+        self.lay = owner._exchange_layout(B)
+        self.recv_fwd: Optional[torch.Tensor] = None
+        self.work = None
+        self.grad_recv: Optional[torch.Tensor] = None
+        self.bwd_work = None
+
+    def start_forward(self, emb: torch.Tensor) -> None:
+        o, lay = self.o, self.lay
+        self.recv_fwd = torch.empty(lay["recv_numel"], dtype=torch.float32, device=emb.device)
+        self.work = dist.all_to_all_single(self.recv_fwd, emb.reshape(-1), output_split_sizes=lay["recv_splits"],
+                                           input_split_sizes=lay["send_splits"], group=o._pg, async_op=True)
+
+    def finish_forward(self) -> torch.Tensor:
+        self.work.wait()
+        self.work = None
+        lay = self.lay
+        return torch.ops.tbe_hip.pooled_exchange_unpack(
+            self.recv_fwd, lay["feat_out_col"], lay["feat_src"], lay["feat_slab_col"], lay["slab_offset"],
+            lay["slab_stride"], self.B, self.o._D_total, self.o._vec_ok, 1.0)
+
+    def dummy_grad(self) -> torch.Tensor:
+        # gradient placeholder for recv_fwd: its real gradient travels through the all-to-all
+        return self.recv_fwd.new_zeros(1).expand(self.recv_fwd.shape)
+
+    def start_backward(self, grad_out: torch.Tensor) -> None:
+        o, lay = self.o, self.lay
+        scale = 1.0 / o._world_size if GRADIENT_DIVISION else 1.0
+        send = torch.ops.tbe_hip.pooled_exchange_pack(
+            grad_out, lay["feat_out_col"], lay["feat_src"], lay["feat_slab_col"], lay["slab_offset"],
+            lay["slab_stride"], lay["recv_numel"], o._vec_ok, scale)
+        self.grad_recv = torch.empty(lay["send_numel"], dtype=torch.float32, device=grad_out.device)
+        self.bwd_work = dist.all_to_all_single(self.grad_recv, send, output_split_sizes=lay["send_splits"],
+                                               input_split_sizes=lay["recv_splits"], group=o._pg, async_op=True)
+        self._send_keepalive = send
+
+    def finish_backward(self) -> torch.Tensor:
+        self.bwd_work.wait()
+        self.bwd_work = None
+        self._send_keepalive = None
+        return self.grad_recv.view(self.o._world_size * self.B, self.o._D_local)
+
+
+class _OutputAwaitable(LazyAwaitable):
+    def __init__(self, fn: Callable[[], KeyedTensor]) -> None:
+        super().__init__()
+        self._fn = fn
+
+    def _wait_impl(self) -> KeyedTensor:
+        return self._fn()
+
+
+class EmbeddingFusedOptimizer:
+    """Optimizer facade over the TBE's in-backward optimizer
+    (torchrec/distributed/batched_embedding_kernel.py:53-257): `step()`/`zero_grad()` only push
+    the learning rate; parameters are the local table shards."""
+
+    def __init__(self, emb_module, table_names: List[str]) -> None:
+        self._emb_module = emb_module
+        weights = emb_module.split_embedding_weights()
+        self.params: Dict[str, torch.Tensor] = {f"{n}.weight": w for n, w in zip(table_names, weights)}
+        self.param_groups = [{"params": list(self.params.values()),
+                              "lr": emb_module.optimizer_args.learning_rate}]
+        self.state: Dict[str, Any] = {}
+        for n, st in zip(table_names, emb_module.split_optimizer_states()):
+            for i, s in enumerate(st):
+                self.state[f"{n}.momentum{i + 1}"] = s
+
+    def zero_grad(self, set_to_none: bool = False) -> None:
+        self._emb_module.set_learning_rate(self.param_groups[0]["lr"])
+
+    def step(self, closure: Any = None) -> None:
+        self._emb_module.set_learning_rate(self.param_groups[0]["lr"])
+
+    def state_dict(self) -> Dict[str, Any]:
+        return {"state": dict(self.state), "param_groups": [{"lr": self.param_groups[0]["lr"]}]}
+
+
+class ShardedEmbeddingBagCollection(nn.Module):
+    def __init__(
+        self,
+        module: EmbeddingBagCollection,
+        table_name_to_parameter_sharding: Dict[str, ParameterSharding],
+        env: ShardingEnv,
+        fused_params: Optional[Dict[str, Any]] = None,
+        device: Optional[torch.device] = None,
+        tbe_factory: Optional[Callable] = None,
+    ) -> None:
+        super().__init__()
+        self._env = env
+        self._pg = env.process_group
+        W, me = env.world_size, env.rank
+        self._world_size, self._rank = W, me
+        self._device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self._is_weighted = module.is_weighted
+        cfgs = module.embedding_bag_configs
+        self._embedding_bag_configs = cfgs
+        poolings = {c.pooling for c in cfgs}
+        if len(poolings) != 1:
+            raise ValueError("all tables must share one pooling type")
+        # ---- global feature list, in the collection's output order -----------------------------
+        self._feature_names: List[str] = []
+        g_table: List[int] = []
+        for t, c in enumerate(cfgs):
+            for f in c.feature_names:
+                self._feature_names.append(f)
+                g_table.append(t)
+        Fg = len(self._feature_names)
+        g_dim = [cfgs[t].embedding_dim for t in g_table]
+        self._lengths_per_embedding = g_dim
+        self._D_total = sum(g_dim)
+        # ---- who holds what --------------------------------------------------------------------
+        kind: List[int] = []  # per table: -1 row-wise, else owning rank
+        for c in cfgs:
+            ps = table_name_to_parameter_sharding[c.name]
+            if ps.sharding_type == ShardingType.ROW_WISE.value:
+                kind.append(-1)
+            elif ps.sharding_type == ShardingType.TABLE_WISE.value:
+                kind.append(int(ps.ranks[0]))
+            else:
+                raise NotImplementedError(f"sharding type {ps.sharding_type} is outside the MI355X hot path "
+                                          "(table_wise / row_wise)")
+        self._table_kind = kind
+        # local feature list of every rank: row-wise features first (same columns on every rank)
+        rw_feats = [g for g in range(Fg) if kind[g_table[g]] < 0]
+        local_feats = [rw_feats + [g for g in range(Fg) if kind[g_table[g]] == r] for r in range(W)]
+        self._local_feats = local_feats
+        self._D_local_per_rank = [sum(g_dim[g] for g in lf) for lf in local_feats]
+        self._D_local = self._D_local_per_rank[me]
+        self._F_local = len(local_feats[me])
+        self._send_feature_order = [g for lf in local_feats for g in lf]
+        self._send_feats_per_rank = [len(lf) for lf in local_feats]
+        # exchange descriptors (batch-independent part)
+        feat_src, feat_slab_col = [0] * Fg, [0] * Fg
+        for r in range(W):
+            col = 0
+            for g in local_feats[r]:
+                if kind[g_table[g]] < 0:
+                    feat_src[g], feat_slab_col[g] = -1, col
+                elif kind[g_table[g]] == r:
+                    feat_src[g], feat_slab_col[g] = r, col
+                col += g_dim[g]
+        out_col = [0]
+        for d in g_dim:
+            out_col.append(out_col[-1] + d)
+        dev = self._device
+        self._feat_out_col = torch.tensor(out_col, dtype=torch.int32, device=dev)
+        self._feat_src = torch.tensor(feat_src, dtype=torch.int32, device=dev)
+        self._feat_slab_col = torch.tensor(feat_slab_col, dtype=torch.int32, device=dev)
+        self._slab_stride = torch.tensor(self._D_local_per_rank, dtype=torch.int32, device=dev)
+        self._vec_ok = all(d % 4 == 0 for d in g_dim)
+        self._layout_cache: Dict[int, Dict[str, Any]] = {}
+        self._kjt_cache: Dict[Tuple, Any] = {}
+        # ---- local tables + TBE ----------------------------------------------------------------
+        self._local_tables: List[_LocalTable] = []
+        local_table_index: Dict[int, int] = {}
+        for g in local_feats[me]:
+            t = g_table[g]
+            if t in local_table_index:
+                continue
+            c = cfgs[t]
+            if kind[t] < 0:
+                rows = rw_shard_rows(c.num_embeddings, W)[me]
+                self._local_tables.append(_LocalTable(c, rows, me * rw_block_size(c.num_embeddings, W), True))
+            else:
+                self._local_tables.append(_LocalTable(c, c.num_embeddings, 0, False))
+            local_table_index[t] = len(self._local_tables) - 1
+        ftm_local = [local_table_index[g_table[g]] for g in local_feats[me]]
+        row_base = [self._local_tables[i].row_offset for i in ftm_local]
+        self._has_rw = any(b != 0 for b in row_base) or any(lt.row_wise for lt in self._local_tables)
+        self._row_base = torch.tensor(row_base, dtype=torch.int64, device=dev).view(1, -1, 1)
+        fused_params = dict(fused_params or {})
+        factory = tbe_factory or _default_tbe_factory
+        self._emb_module = None
+        if self._local_tables:
+            self._emb_module = factory(
+                [(max(lt.local_rows, 0), lt.cfg.embedding_dim) for lt in self._local_tables],
+                ftm_local * W, pooling_type_to_pooling_mode(cfgs[0].pooling), dev, fused_params)
+            if W > 1:
+                self._emb_module.set_a2a_output_layout(W)
+            self._init_parameters()
+            self._optim = EmbeddingFusedOptimizer(self._emb_module, [lt.cfg.name for lt in self._local_tables])
+        else:
+            self._optim = None
+
+    # ---- parameters -----------------------------------------------------------------------------
+    def _init_parameters(self) -> None:
+        # U(-sqrt(1/N), sqrt(1/N)) per table (batched_embedding_kernel.py:530-544)
+        for lt, w in zip(self._local_tables, self._emb_module.split_embedding_weights()):
+            if w.numel():
+                w.uniform_(lt.cfg.get_weight_init_min(), lt.cfg.get_weight_init_max())
+
+    @property
+    def fused_optimizer(self) -> Optional[EmbeddingFusedOptimizer]:
+        return self._optim
+
+    @property
+    def embedding_bag_configs(self) -> List[EmbeddingBagConfig]:
+        return self._embedding_bag_configs
+
+    def local_shards(self) -> Dict[str, Tuple[torch.Tensor, int]]:
+        """table name -> (local weight shard [rows_local, D], first global row of the shard)."""
+        if self._emb_module is None:
+            return {}
+        return {lt.cfg.name: (w, lt.row_offset)
+                for lt, w in zip(self._local_tables, self._emb_module.split_embedding_weights())}
+
+    def state_dict(self, destination=None, prefix: str = "", keep_vars: bool = False):
+        destination = {} if destination is None else destination
+        for name, (w, _) in self.local_shards().items():
+            destination[f"{prefix}embedding_bags.{name}.weight"] = w  # key as embeddingbag.py:416
+        return destination
+
+    def named_parameters(self, prefix: str = "", recurse: bool = True) -> Iterator[Tuple[str, nn.Parameter]]:
+        yield from ()  # fused: weights are updated inside backward (batched_embedding_kernel.py:655-658)
+
+    # ---- layouts --------------------------------------------------------------------------------
+    def _exchange_layout(self, B: int) -> Dict[str, Any]:
+        lay = self._layout_cache.get(B)
+        if lay is None:
+            W = self._world_size
+            offs, o = [], 0
+            for r in range(W):
+                offs.append(o)
+                o += B * self._D_local_per_rank[r]
+            lay = {
+                "slab_offset": torch.tensor(offs, dtype=torch.int64, device=self._device),
+                "slab_stride": self._slab_stride,
+                "feat_out_col": self._feat_out_col, "feat_src": self._feat_src, "feat_slab_col": self._feat_slab_col,
+                "recv_splits": [B * d for d in self._D_local_per_rank], "recv_numel": o,
+                "send_splits": [B * self._D_local] * W, "send_numel": W * B * self._D_local,
+            }
+            self._layout_cache[B] = lay
+        return lay
+
+    # ---- input dist -----------------------------------------------------------------------------
+    def _send_perm(self, keys: List[str]) -> torch.Tensor:
+        ck = ("perm", tuple(keys))
+        hit = self._kjt_cache.get(ck)
+        if hit is None:
+            pos = {k: i for i, k in enumerate(keys)}
+            missing = [n for n in self._feature_names if n not in pos]
+            if missing:
+                raise KeyError(f"KeyedJaggedTensor is missing features {missing[:3]}...")
+            order = [pos[self._feature_names[g]] for g in self._send_feature_order]
+            hit = (order, torch.tensor(order, dtype=torch.int64, device=self._device))
+            self._kjt_cache[ck] = hit
+        return hit
+
+    def input_dist(self, features: KeyedJaggedTensor) -> Awaitable[SparseFeaturesDist]:
+        W, B = self._world_size, features.stride()
+        order, order_t = self._send_perm(features.keys())
+        fixed = features.fixed_lengths()
+        weights = features.weights_or_none() if self._is_weighted else None
+        if fixed is not None and len(set(fixed)) == 1 and fixed[0] > 0:
+            L = fixed[0]
+            nkeys = len(features.keys())
+            send_v = features.values().view(nkeys, B * L).index_select(0, order_t)
+            send_w = weights.view(nkeys, B * L).index_select(0, order_t) if weights is not None else None
+            in_splits = [n * B * L for n in self._send_feats_per_rank]
+            out_splits = [self._F_local * B * L] * W
+            if W > 1:
+                recv_v = torch.empty(sum(out_splits), dtype=send_v.dtype, device=send_v.device)
+                wk = dist.all_to_all_single(recv_v, send_v.view(-1), out_splits, in_splits, group=self._pg, async_op=True)
+                recv_w, wk2 = None, None
+                if send_w is not None:
+                    recv_w = torch.empty(sum(out_splits), dtype=send_w.dtype, device=send_w.device)
+                    wk2 = dist.all_to_all_single(recv_w, send_w.view(-1), out_splits, in_splits, group=self._pg, async_op=True)
+            else:
+                recv_v, recv_w, wk, wk2 = send_v.reshape(-1), (send_w.reshape(-1) if send_w is not None else None), None, None
+
+            def finish() -> SparseFeaturesDist:
+                if wk is not None:
+                    wk.wait()
+                if wk2 is not None:
+                    wk2.wait()
+                vals = recv_v
+                if self._has_rw:
+                    vals = (recv_v.view(W, self._F_local, B * L) - self._row_base).view(-1)
+                ck = ("off", B, L)
+                offsets = self._kjt_cache.get(ck)
+                if offsets is None:
+                    offsets = torch.arange(W * self._F_local * B + 1, dtype=torch.int64, device=self._device) * L
+                    self._kjt_cache[ck] = offsets
+                return SparseFeaturesDist(vals, offsets, recv_w, B)
+
+            return _InputDistAwaitable(finish)
+        # ---- data-dependent pooling factors: lengths a2a, D2H of the value counts, values a2a
+        #      (the reference's 2-phase KJTAllToAll, dist_data.py:137-524) -----------------------
+        sent = features.permute(order, None)
+        lengths = sent.lengths()
+        lpk = sent.length_per_key()
+        n_per_rank = self._send_feats_per_rank
+        len_in = [n * B for n in n_per_rank]
+        len_out = [self._F_local * B] * W
+        val_in, k = [], 0
+        for n in n_per_rank:
+            val_in.append(sum(lpk[k:k + n]))
+            k += n
+        if W > 1:
+            recv_l = torch.empty(sum(len_out), dtype=lengths.dtype, device=lengths.device)
+            dist.all_to_all_single(recv_l, lengths, len_out, len_in, group=self._pg)
+            val_out = recv_l.view(W, -1).sum(dim=1).cpu().tolist()  # host sync (dist_data.py:396-398)
+            recv_v = torch.empty(sum(val_out), dtype=sent.values().dtype, device=lengths.device)
+            wk = dist.all_to_all_single(recv_v, sent.values(), val_out, val_in, group=self._pg, async_op=True)
+            recv_w, wk2 = None, None
+            if weights is not None:
+                recv_w = torch.empty(sum(val_out), dtype=weights.dtype, device=lengths.device)
+                wk2 = dist.all_to_all_single(recv_w, sent.weights(), val_out, val_in, group=self._pg, async_op=True)
+        else:
+            recv_l, recv_v, recv_w, wk, wk2 = lengths, sent.values(), sent.weights_or_none() if weights is not None else None, None, None
+
+        def finish_var() -> SparseFeaturesDist:
+            if wk is not None:
+                wk.wait()
+            if wk2 is not None:
+                wk2.wait()
+            offsets = torch.ops.fbgemm.asynchronous_complete_cumsum(recv_l).long()
+            vals = recv_v
+            if self._has_rw:
+                # subtract the row-wise block start per (src, local feature) segment
+                seg = torch.repeat_interleave(
+                    self._row_base.view(1, -1).expand(W, -1).reshape(-1),
+                    recv_l.view(W * self._F_local, B).sum(dim=1).long())
+                vals = recv_v - seg
+            return SparseFeaturesDist(vals, offsets, recv_w, B)
+
+        return _InputDistAwaitable(finish_var)
+
+    # ---- compute + output dist ------------------------------------------------------------------
+    def compute_and_output_dist(self, dist_input: SparseFeaturesDist) -> Awaitable[KeyedTensor]:
+        B = dist_input.batch_size
+        keys, lpe = self._feature_names, self._lengths_per_embedding
+        if self._emb_module is not None:
+            emb = self._emb_module(dist_input.values, dist_input.offsets, dist_input.weights)
+        else:
+            emb = torch.zeros((self._world_size * B, 0), dtype=torch.float32, device=self._device)
+        if self._world_size == 1:
+            return NoWait(KeyedTensor(keys, lpe, emb))
+        state = _ExchangeState(self, B)
+        recv = _ExchangeReq.apply(emb, state)
+        return _OutputAwaitable(lambda: KeyedTensor(keys, lpe, _ExchangeWait.apply(recv, state)))
+
+    def forward(self, features: KeyedJaggedTensor) -> Awaitable[KeyedTensor]:
+        return self.compute_and_output_dist(self.input_dist(features).wait())
+
+
+class EmbeddingBagCollectionSharder:
+    """Builds the sharded module from an EmbeddingBagCollection + per-table plan
+    (torchrec/distributed/embeddingbag.py:489-515)."""
+
+    def __init__(self, fused_params: Optional[Dict[str, Any]] = None, tbe_factory: Optional[Callable] = None) -> None:
+        self.fused_params = fused_params
+        self.tbe_factory = tbe_factory
+
+    def shard(self, module: EmbeddingBagCollection, params: Dict[str, ParameterSharding], env: ShardingEnv,
+              device: Optional[torch.device] = None) -> ShardedEmbeddingBagCollection:
+        return ShardedEmbeddingBagCollection(module, params, env, self.fused_params, device, self.tbe_factory)
+
+    @property
+    def module_type(self):
+        return EmbeddingBagCollection

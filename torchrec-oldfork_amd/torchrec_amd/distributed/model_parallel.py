@@ -1,0 +1,94 @@
+"""DistributedModelParallel for the MI355X path (torchrec/distributed/model_parallel.py:162-527):
+replaces every EmbeddingBagCollection in `module` by a ShardedEmbeddingBagCollection according to
+the plan (planner on rank 0 semantics: the plan is a pure function of the configs, so every
+rank computes the same one — no broadcast_object_list needed), and wraps the remaining dense
+parameters in DistributedDataParallel (model_parallel.py:84-111) when world_size > 1."""
+from typing import Dict, Iterator, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+from torch import nn
+from torch.nn.parallel import DistributedDataParallel
+
+from ..modules.embedding_modules import EmbeddingBagCollection
+from ..optim.keyed import CombinedOptimizer
+from .embeddingbag import EmbeddingBagCollectionSharder, ShardedEmbeddingBagCollection
+from .planner import EmbeddingShardingPlanner, Topology
+from .types import ShardingEnv, ShardingPlan
+
+
+class DistributedModelParallel(nn.Module):
+    def __init__(self, module: nn.Module, env: Optional[ShardingEnv] = None, device: Optional[torch.device] = None,
+                 plan: Optional[ShardingPlan] = None, sharders: Optional[List[EmbeddingBagCollectionSharder]] = None,
+                 init_data_parallel: bool = True, planner: Optional[EmbeddingShardingPlanner] = None) -> None:
+        super().__init__()
+        if env is None:
+            pg = dist.group.WORLD if dist.is_initialized() else None
+            env = ShardingEnv.from_process_group(pg) if pg is not None else ShardingEnv.from_local(1, 0)
+        self._env = env
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        sharder = (sharders or [EmbeddingBagCollectionSharder()])[0]
+        planner = planner or EmbeddingShardingPlanner(Topology(env.world_size, self.device.type))
+        self._plan = plan or ShardingPlan()
+        self._sharded: List[ShardedEmbeddingBagCollection] = []
+        self._shard_modules(module, "", sharder, planner)
+        self._dmp_wrapped_module = module
+        self._ddp_wrapped = False
+        if init_data_parallel:
+            self.init_data_parallel()
+
+    def _shard_modules(self, module: nn.Module, path: str, sharder, planner) -> None:
+        for name, child in list(module.named_children()):
+            child_path = f"{path}.{name}" if path else name
+            if isinstance(child, EmbeddingBagCollection):
+                params = self._plan.get_plan_for_module(child_path)
+                if params is None:
+                    params = planner.plan_tables(child.embedding_bag_configs)
+                    self._plan.plan[child_path] = params
+                sharded = sharder.shard(child, params, self._env, self.device)
+                setattr(module, name, sharded)
+                self._sharded.append(sharded)
+            else:
+                self._shard_modules(child, child_path, sharder, planner)
+
+    def init_data_parallel(self) -> None:
+        if self._ddp_wrapped:
+            return
+        m = self._dmp_wrapped_module
+        dense = [p for _, p in self._dense_named_parameters(m)]
+        for p in dense:
+            if p.device != self.device:
+                raise RuntimeError("dense parameters must live on the DMP device")
+        if self._env.world_size > 1 and dense:
+            self._dmp_wrapped_module = DistributedDataParallel(
+                m, device_ids=[self.device.index] if self.device.type == "cuda" else None,
+                process_group=self._env.process_group, gradient_as_bucket_view=True, broadcast_buffers=False,
+                static_graph=True)
+        self._ddp_wrapped = True
+
+    @staticmethod
+    def _dense_named_parameters(m: nn.Module) -> Iterator[Tuple[str, nn.Parameter]]:
+        # torch's named_parameters: sharded tables expose none (they are fused)
+        yield from m.named_parameters()
+
+    @property
+    def module(self) -> nn.Module:
+        m = self._dmp_wrapped_module
+        return m.module if isinstance(m, DistributedDataParallel) else m
+
+    @property
+    def plan(self) -> ShardingPlan:
+        return self._plan
+
+    def sharded_modules(self) -> List[ShardedEmbeddingBagCollection]:
+        return self._sharded
+
+    @property
+    def fused_optimizer(self) -> CombinedOptimizer:
+        return CombinedOptimizer([s.fused_optimizer for s in self._sharded if s.fused_optimizer is not None])
+
+    def forward(self, *args, **kwargs):
+        return self._dmp_wrapped_module(*args, **kwargs)
+
+    def named_parameters(self, prefix: str = "", recurse: bool = True):
+        yield from self.module.named_parameters(prefix=prefix, recurse=recurse)

@@ -1,0 +1,107 @@
+"""Sharding planner with an MI355X hardware model.
+
+Plays the role of EmbeddingShardingPlanner (torchrec/distributed/planner/planners.py:126-309)
+for the sharding types on this build's hot path (table-wise, row-wise).  The reference's
+perf constants are A100-era (planner/constants.py:14-73: HBM 32 GiB / 897 GB/s, intra-node
+600 GB/s); these are MI355X's (288 GB HBM3E, ~6.3 TB/s achievable, 7 xGMI links x ~153 GB/s,
+all-to-all uses every link at once).
+
+Cost model per (table, rank): a pooled lookup moves B_global * L * D * 4 bytes from HBM and
+B_global * D * 4 bytes over xGMI regardless of the table's row count, so balancing the NUMBER
+of (feature, dim) units per rank balances both.  Table-wise placement is a greedy
+longest-processing-time fill (as planner/partitioners.py:181-197 does by perf); because F tables
+rarely divide evenly over W ranks, the `F mod W` largest tables are row-wise sharded — every
+rank then carries exactly the same lookup volume — which is also what spreads the tables that
+would not fit one HBM.
+"""
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+from ..modules.embedding_configs import EmbeddingBagConfig
+from .types import EmbeddingComputeKernel, ParameterSharding, ShardingPlan, ShardingType, ShardMetadata
+
+GiB = 1 << 30
+
+
+@dataclass
+class Topology:
+    """planner/types.py:65-108 with MI355X defaults."""
+
+    world_size: int
+    compute_device: str = "cuda"
+    hbm_cap: int = 288 * 10**9
+    hbm_mem_bw: float = 6.3e12
+    intra_host_bw: float = 7 * 153e9
+    hbm_reserve_fraction: float = 0.15  # activations, workspaces, dense model, allocator slack
+
+
+def rw_block_size(rows: int, world_size: int) -> int:
+    """ceil(rows / W): row-wise block size (sharding/rw_sharding.py:229-236)."""
+    return (rows + world_size - 1) // world_size
+
+
+def rw_shard_rows(rows: int, world_size: int) -> List[int]:
+    """Rows held by each rank, e.g. 10 rows / 3 ranks -> [4, 4, 2]; 5 / 4 -> [2, 2, 1, 0]
+    (planner/enumerators.py:277-312)."""
+    blk = rw_block_size(rows, world_size)
+    return [max(0, min(blk, rows - r * blk)) for r in range(world_size)]
+
+
+class EmbeddingShardingPlanner:
+    def __init__(self, topology: Topology, constraints: Optional[Dict[str, List[str]]] = None,
+                 num_row_wise: Optional[int] = None) -> None:
+        self.topology = topology
+        self.constraints = constraints or {}
+        self.num_row_wise = num_row_wise
+
+    def plan_tables(self, tables: List[EmbeddingBagConfig]) -> Dict[str, ParameterSharding]:
+        W = self.topology.world_size
+        cap = int(self.topology.hbm_cap * (1.0 - self.topology.hbm_reserve_fraction))
+        size = {t.name: t.num_embeddings * t.embedding_dim * 4 for t in tables}
+        by_size = sorted(tables, key=lambda t: (-size[t.name], t.name))
+        forced_rw = {n for n, c in self.constraints.items() if c == [ShardingType.ROW_WISE.value]}
+        forced_tw = {n for n, c in self.constraints.items() if c == [ShardingType.TABLE_WISE.value]}
+        n_rw = self.num_row_wise if self.num_row_wise is not None else (len(tables) % W if W > 1 else 0)
+        rw = set(forced_rw)
+        for t in by_size:
+            if W > 1 and size[t.name] > cap:
+                rw.add(t.name)  # does not fit one GPU
+        for t in by_size:
+            if len(rw) >= max(n_rw, len(forced_rw)) or W == 1:
+                break
+            if t.name not in forced_tw:
+                rw.add(t.name)
+        # greedy longest-processing-time fill of the table-wise tables
+        units = [0.0] * W
+        mem = [sum(rw_shard_rows(t.num_embeddings, W)[r] * t.embedding_dim * 4 for t in tables if t.name in rw)
+               for r in range(W)]
+        out: Dict[str, ParameterSharding] = {}
+        kernel = EmbeddingComputeKernel.BATCHED_FUSED.value
+        for t in by_size:
+            if t.name in rw:
+                rows = rw_shard_rows(t.num_embeddings, W)
+                off = 0
+                spec = []
+                for r in range(W):
+                    spec.append(ShardMetadata([off, 0], [rows[r], t.embedding_dim], f"rank:{r}/cuda:{r}"))
+                    off += rows[r]
+                out[t.name] = ParameterSharding(ShardingType.ROW_WISE.value, kernel, list(range(W)), spec)
+                continue
+            cost = float(t.num_features() * t.embedding_dim)
+            order = sorted(range(W), key=lambda r: (units[r], mem[r], r))
+            placed = False
+            for r in order:
+                if mem[r] + size[t.name] <= cap:
+                    units[r] += cost
+                    mem[r] += size[t.name]
+                    out[t.name] = ParameterSharding(
+                        ShardingType.TABLE_WISE.value, kernel, [r],
+                        [ShardMetadata([0, 0], [t.num_embeddings, t.embedding_dim], f"rank:{r}/cuda:{r}")])
+                    placed = True
+                    break
+            if not placed:
+                raise RuntimeError(f"planner: table {t.name} ({size[t.name] / GiB:.1f} GiB) does not fit any rank")
+        return {t.name: out[t.name] for t in tables}
+
+    def plan(self, module, module_path: str = "") -> ShardingPlan:
+        return ShardingPlan({module_path: self.plan_tables(module.embedding_bag_configs)})

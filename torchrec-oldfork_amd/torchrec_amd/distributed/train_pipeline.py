@@ -1,0 +1,117 @@
+"""TrainPipelineSparseDist for the MI355X path (torchrec/distributed/train_pipeline.py:422-558).
+
+Same three stages and stream roles as the reference — (1) host->device copy of batch i+2 on a
+memcpy stream, (2) input_dist (id all-to-all) of batch i+1 on a data_dist stream, (3)
+forward/backward/optimizer of batch i on the default stream — without the reference fork's
+debug file write on the hot loop (train_pipeline.py:538-544) and without fx tracing: the model
+exposes its sharded modules directly (DistributedModelParallel.sharded_modules()), and the
+pipelined forward is injected through `set_precomputed_input_dist`.
+"""
+from typing import Any, Iterator, List, Optional, Tuple
+
+import torch
+
+from .model_parallel import DistributedModelParallel
+
+
+class _PipelinedEBC(torch.nn.Module):
+    """Stands in for a ShardedEmbeddingBagCollection during a pipelined step: forward() consumes the
+    input_dist result computed earlier on the data_dist stream (train_pipeline.py:193-243)."""
+
+    def __init__(self, sharded, pipeline: "TrainPipelineSparseDist") -> None:
+        super().__init__()
+        self.sharded = sharded
+        self.pipeline = pipeline
+        self.embedding_bag_configs = sharded.embedding_bag_configs
+
+    def forward(self, features):
+        req = self.pipeline._requests.pop(id(self.sharded), None)
+        if req is None:
+            return self.sharded(features)
+        cur = torch.cuda.current_stream()
+        with torch.cuda.stream(self.pipeline._data_dist_stream):
+            dist_in = req.wait()
+        cur.wait_stream(self.pipeline._data_dist_stream)
+        dist_in.record_stream(cur)
+        return self.sharded.compute_and_output_dist(dist_in)
+
+
+class TrainPipelineSparseDist:
+    def __init__(self, model: torch.nn.Module, optimizer: Any, device: torch.device) -> None:
+        self._model, self._optimizer, self._device = model, optimizer, device
+        use_streams = device.type == "cuda"
+        self._memcpy_stream = torch.cuda.Stream(device) if use_streams else None
+        self._data_dist_stream = torch.cuda.Stream(device) if use_streams else None
+        self._requests = {}
+        self._batch_i = None
+        self._batch_ip1 = None
+        self._batch_ip2 = None
+        self._connected = False
+        dmp = model if isinstance(model, DistributedModelParallel) else None
+        self._sharded = dmp.sharded_modules() if dmp is not None else []
+        self._install()
+
+    def _install(self) -> None:
+        root = self._model.module if isinstance(self._model, DistributedModelParallel) else self._model
+        ids = {id(s): s for s in self._sharded}
+
+        def walk(m):
+            for name, child in list(m.named_children()):
+                if id(child) in ids:
+                    setattr(m, name, _PipelinedEBC(child, self))
+                elif not isinstance(child, _PipelinedEBC):
+                    walk(child)
+
+        walk(root)
+
+    def _to_device(self, batch, non_blocking: bool):
+        return batch.to(self._device, non_blocking=non_blocking) if batch is not None else None
+
+    def _start_data_dist(self, batch) -> None:
+        for s in self._sharded:
+            self._requests[id(s)] = s.input_dist(batch.sparse_features)
+
+    def _fill(self, it: Iterator) -> None:
+        if self._memcpy_stream is None:
+            self._batch_i = self._to_device(next(it), False)
+            self._batch_ip1 = self._to_device(next(it, None), False)
+            self._connected = True
+            return
+        with torch.cuda.stream(self._memcpy_stream):
+            self._batch_i = self._to_device(next(it), True)
+            self._batch_ip1 = self._to_device(next(it, None), True)
+        with torch.cuda.stream(self._data_dist_stream):
+            self._data_dist_stream.wait_stream(self._memcpy_stream)
+            self._start_data_dist(self._batch_i)
+        self._connected = True
+
+    def progress(self, dataloader_iter: Iterator) -> Tuple[torch.Tensor, Any]:
+        if not self._connected:
+            self._fill(dataloader_iter)
+        if self._batch_i is None:
+            raise StopIteration
+        if self._memcpy_stream is not None:
+            with torch.cuda.stream(self._memcpy_stream):
+                self._batch_ip2 = self._to_device(next(dataloader_iter, None), True)
+            torch.cuda.current_stream().wait_stream(self._data_dist_stream)
+        else:
+            self._batch_ip2 = self._to_device(next(dataloader_iter, None), False)
+        batch = self._batch_i
+        if self._model.training:
+            self._optimizer.zero_grad()
+        fwd_event = torch.cuda.Event() if self._data_dist_stream is not None else None
+        if fwd_event is not None:
+            fwd_event.record()
+        losses, output = self._model(batch)
+        # input_dist of batch i+1 on the side stream, overlapping fwd/bwd of batch i
+        if self._batch_ip1 is not None:
+            if self._data_dist_stream is not None:
+                with torch.cuda.stream(self._data_dist_stream):
+                    self._data_dist_stream.wait_stream(self._memcpy_stream)
+                    self._data_dist_stream.wait_event(fwd_event)
+                    self._start_data_dist(self._batch_ip1)
+        if self._model.training:
+            torch.sum(losses, dim=0).backward()
+            self._optimizer.step()
+        self._batch_i, self._batch_ip1 = self._batch_ip1, self._batch_ip2
+        return losses, output

@@ -1,0 +1,132 @@
+"""DLRM dense side + model wrapper (torchrec/models/dlrm.py:36-406,
+examples/dlrm/modules/dlrm_train.py).  Module and parameter names follow the reference so
+state_dict keys are interchangeable (`dense_arch.model._mlp.0._linear.weight`,
+`over_arch.model.1.bias`, ...).  The dense MLPs and the dot interaction are the only MFMA
+users of the path (rocBLAS/hipBLASLt fp32 GEMMs)."""
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from ..modules.mlp import MLP
+from ..sparse.jagged_tensor import KeyedJaggedTensor, KeyedTensor
+
+
+class SparseArch(nn.Module):
+    """models/dlrm.py:36-113: pooled embeddings -> [B, F, D]."""
+
+    def __init__(self, embedding_bag_collection: nn.Module) -> None:
+        super().__init__()
+        self.embedding_bag_collection = embedding_bag_collection
+        cfgs = embedding_bag_collection.embedding_bag_configs
+        assert cfgs, "Embedding bag collection cannot be empty!"
+        self.D: int = cfgs[0].embedding_dim
+        self._sparse_feature_names: List[str] = [n for c in cfgs for n in c.feature_names]
+        self.F: int = len(self._sparse_feature_names)
+
+    def start(self, features: KeyedJaggedTensor):
+        """Issues the lookup (and, when sharded, the pooled all-to-all) and returns without waiting."""
+        return self.embedding_bag_collection(features)
+
+    def finish(self, pending) -> torch.Tensor:
+        sparse_features = pending.wait() if hasattr(pending, "wait") else pending
+        B = sparse_features.values().shape[0]
+        if sparse_features.keys() == self._sparse_feature_names:
+            return sparse_features.values().reshape(B, self.F, self.D)
+        sparse: Dict[str, torch.Tensor] = sparse_features.to_dict()
+        return torch.cat([sparse[n] for n in self._sparse_feature_names], dim=1).reshape(B, self.F, self.D)
+
+    def forward(self, features: KeyedJaggedTensor) -> torch.Tensor:
+        return self.finish(self.start(features))
+
+    @property
+    def sparse_feature_names(self) -> List[str]:
+        return self._sparse_feature_names
+
+
+class DenseArch(nn.Module):
+    def __init__(self, in_features: int, layer_sizes: List[int], device: Optional[torch.device] = None) -> None:
+        super().__init__()
+        self.model = MLP(in_features, layer_sizes, bias=True, activation="relu", device=device)
+
+    def forward(self, features: torch.Tensor) -> torch.Tensor:
+        return self.model(features)
+
+
+class InteractionArch(nn.Module):
+    """models/dlrm.py:193-219: [dense | upper-triangle of (dense,sparse)x(dense,sparse)^T]."""
+
+    def __init__(self, num_sparse_features: int) -> None:
+        super().__init__()
+        self.F = num_sparse_features
+        self.register_buffer("triu_indices", torch.triu_indices(self.F + 1, self.F + 1, offset=1), persistent=False)
+
+    def forward(self, dense_features: torch.Tensor, sparse_features: torch.Tensor) -> torch.Tensor:
+        if self.F <= 0:
+            return dense_features
+        combined = torch.cat((dense_features.unsqueeze(1), sparse_features), dim=1)
+        interactions = torch.bmm(combined, combined.transpose(1, 2))
+        flat = interactions[:, self.triu_indices[0], self.triu_indices[1]]
+        return torch.cat((dense_features, flat), dim=1)
+
+
+class OverArch(nn.Module):
+    def __init__(self, in_features: int, layer_sizes: List[int], device: Optional[torch.device] = None) -> None:
+        super().__init__()
+        if len(layer_sizes) <= 1:
+            raise ValueError("OverArch must have multiple layers.")
+        self.model = nn.Sequential(
+            MLP(in_features, layer_sizes[:-1], bias=True, activation="relu", device=device),
+            nn.Linear(layer_sizes[-2], layer_sizes[-1], bias=True, device=device))
+
+    def forward(self, features: torch.Tensor) -> torch.Tensor:
+        return self.model(features)
+
+
+class DLRM(nn.Module):
+    def __init__(self, embedding_bag_collection: nn.Module, dense_in_features: int,
+                 dense_arch_layer_sizes: List[int], over_arch_layer_sizes: List[int],
+                 dense_device: Optional[torch.device] = None) -> None:
+        super().__init__()
+        cfgs = embedding_bag_collection.embedding_bag_configs
+        assert len(cfgs) > 0, "At least one embedding bag is required"
+        D = cfgs[0].embedding_dim
+        assert all(c.embedding_dim == D for c in cfgs), "All EmbeddingBagConfigs must have the same dimension"
+        if dense_arch_layer_sizes[-1] != D:
+            raise ValueError(f"embedding_bag_collection dimension ({D}) and final dense arch layer size "
+                             f"({dense_arch_layer_sizes[-1]}) must match.")
+        self.sparse_arch = SparseArch(embedding_bag_collection)
+        F = self.sparse_arch.F
+        self.dense_arch = DenseArch(dense_in_features, dense_arch_layer_sizes, device=dense_device)
+        self.inter_arch = InteractionArch(F)
+        over_in = D + (F + 1) * F // 2
+        self.over_arch = OverArch(over_in, over_arch_layer_sizes, device=dense_device)
+        if dense_device is not None:
+            self.inter_arch.to(dense_device)
+
+    def forward(self, dense_features: torch.Tensor, sparse_features: KeyedJaggedTensor) -> torch.Tensor:
+        # The reference runs dense_arch, then sparse_arch (models/dlrm.py:400-401).  Here the lookup and
+        # the pooled all-to-all are issued first so that the exchange overlaps the bottom MLP on the
+        # collective's own HIP stream; the two branches are independent, results are identical.
+        pending = self.sparse_arch.start(sparse_features)
+        embedded_dense = self.dense_arch(dense_features)
+        embedded_sparse = self.sparse_arch.finish(pending)
+        concatenated = self.inter_arch(dense_features=embedded_dense, sparse_features=embedded_sparse)
+        return self.over_arch(concatenated)
+
+
+class DLRMTrain(nn.Module):
+    """examples/dlrm/modules/dlrm_train.py: BCEWithLogits wrapper used by the train pipeline."""
+
+    def __init__(self, embedding_bag_collection: nn.Module, dense_in_features: int,
+                 dense_arch_layer_sizes: List[int], over_arch_layer_sizes: List[int],
+                 dense_device: Optional[torch.device] = None) -> None:
+        super().__init__()
+        self.model = DLRM(embedding_bag_collection, dense_in_features, dense_arch_layer_sizes,
+                          over_arch_layer_sizes, dense_device)
+        self.loss_fn = nn.BCEWithLogitsLoss()
+
+    def forward(self, batch) -> Tuple[torch.Tensor, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
+        logits = self.model(batch.dense_features, batch.sparse_features).squeeze(-1)
+        loss = self.loss_fn(logits, batch.labels.float())
+        return loss, (loss.detach(), logits.detach(), batch.labels.detach())
