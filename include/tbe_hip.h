@@ -248,6 +248,21 @@ int tbe_pooled_exchange_pack(const float* grad, float* send, const int32_t* feat
                              int32_t Fg, int32_t W, int32_t B_local, int32_t D_total,
                              int32_t all_multiple_of_4, float scale, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Fused DLRM dot interaction (the path's only MFMA user): InteractionArch.forward,
+ * torchrec/models/dlrm.py:193-219 — cat + bmm(X, X^T) + triu gather + cat — and its autograd
+ * backward, each as one kernel on v_mfma_f32_16x16x4_f32 (exact f32).
+ *   dense [B, D], sparse [B, F, D] contiguous, out / grad_out [B, D + (F+1)F/2]:
+ *   out[b] = [dense[b] | <X_i, X_j> for i < j in torch.triu_indices(F+1, F+1, 1) order],
+ *   X = [dense[b]; sparse[b]].
+ * forward: 1 <= F <= 31, D % 4 == 0, D <= 256.  backward: F <= 27, D in {16, 32, 64, 128}.
+ * ---------------------------------------------------------------------------------- */
+int tbe_dlrm_interaction_forward_f32(const float* dense, const float* sparse, int32_t B,
+                                     int32_t F, int32_t D, float* out, void* stream);
+int tbe_dlrm_interaction_backward_f32(const float* dense, const float* sparse,
+                                      const float* grad_out, int32_t B, int32_t F, int32_t D,
+                                      float* grad_dense, float* grad_sparse, void* stream);
+
 /* torch.ops.fbgemm.jagged_2d_to_dense (examples/bert4rec/models/bert4rec.py:394-400):
  * values [N, D] + offsets [B+1] -> dense [B, max_L, D], zero padded / truncated. */
 int tbe_jagged_2d_to_dense_f32(const float* values, const int64_t* offsets, int32_t B,

@@ -192,6 +192,27 @@ def jagged_2d_to_dense(values, offsets, max_L: int) -> np.ndarray:
     return dense
 
 
+def interaction_forward(dense, sparse) -> np.ndarray:
+    """dense [B, D], sparse [B, F, D] -> [B, D + (F+1)F/2] (oracle/dlrm_oracle.c)."""
+    dense = _c(dense, np.float32)
+    sparse = _c(sparse, np.float32)
+    B, F, D = sparse.shape
+    out = np.zeros((B, D + (F + 1) * F // 2), dtype=np.float32)
+    lib().oracle_interaction_forward(_p(dense), _p(sparse), B, F, D, _p(out))
+    return out
+
+
+def interaction_backward(dense, sparse, grad_out) -> Tuple[np.ndarray, np.ndarray]:
+    dense = _c(dense, np.float32)
+    sparse = _c(sparse, np.float32)
+    grad_out = _c(grad_out, np.float32)
+    B, F, D = sparse.shape
+    gd = np.zeros((B, D), dtype=np.float32)
+    gs = np.zeros((B, F, D), dtype=np.float32)
+    lib().oracle_interaction_backward(_p(dense), _p(sparse), _p(grad_out), B, F, D, _p(gd), _p(gs))
+    return gd, gs
+
+
 def offsets_range(offsets, range_size: int) -> np.ndarray:
     offsets = _c(offsets, np.int64)
     out = np.zeros(range_size, dtype=np.int64)

@@ -53,17 +53,62 @@ class DenseArch(nn.Module):
         return self.model(features)
 
 
+class _FusedDotInteraction(torch.autograd.Function):
+    """One HIP kernel each way (csrc/dlrm_interaction.hip, fp32 MFMA) instead of the reference's
+    cat + bmm + index + cat chain and its autograd backward (models/dlrm.py:206-219)."""
+
+    @staticmethod
+    def forward(ctx, dense, sparse):
+        from fbgemm_gpu import _lib
+        from fbgemm_gpu._lib import check, ptr, stream_ptr
+
+        dense, sparse = dense.contiguous(), sparse.contiguous()
+        B, F, D = sparse.shape
+        out = torch.empty((B, D + (F + 1) * F // 2), dtype=torch.float32, device=dense.device)
+        with torch.cuda.device(dense.device):
+            check(_lib.load().tbe_dlrm_interaction_forward_f32(ptr(dense), ptr(sparse), B, F, D, ptr(out),
+                                                               stream_ptr(dense.device)),
+                  "tbe_dlrm_interaction_forward_f32")
+        ctx.save_for_backward(dense, sparse)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from fbgemm_gpu import _lib
+        from fbgemm_gpu._lib import check, ptr, stream_ptr
+
+        dense, sparse = ctx.saved_tensors
+        B, F, D = sparse.shape
+        grad_out = grad_out.contiguous()
+        gd, gs = torch.empty_like(dense), torch.empty_like(sparse)
+        with torch.cuda.device(dense.device):
+            check(_lib.load().tbe_dlrm_interaction_backward_f32(ptr(dense), ptr(sparse), ptr(grad_out), B, F, D,
+                                                                ptr(gd), ptr(gs), stream_ptr(dense.device)),
+                  "tbe_dlrm_interaction_backward_f32")
+        return gd, gs
+
+
+def _fused_interaction_ok(dense: torch.Tensor, sparse: torch.Tensor) -> bool:
+    F, D = sparse.shape[1], sparse.shape[2]
+    return (dense.is_cuda and dense.dtype == torch.float32 and sparse.dtype == torch.float32
+            and 1 <= F <= 27 and D in (16, 32, 64, 128))
+
+
 class InteractionArch(nn.Module):
     """models/dlrm.py:193-219: [dense | upper-triangle of (dense,sparse)x(dense,sparse)^T]."""
 
     def __init__(self, num_sparse_features: int) -> None:
         super().__init__()
         self.F = num_sparse_features
+        self.fused = True
         self.register_buffer("triu_indices", torch.triu_indices(self.F + 1, self.F + 1, offset=1), persistent=False)
 
     def forward(self, dense_features: torch.Tensor, sparse_features: torch.Tensor) -> torch.Tensor:
         if self.F <= 0:
             return dense_features
+        if self.fused and _fused_interaction_ok(dense_features, sparse_features):
+            return _FusedDotInteraction.apply(dense_features, sparse_features)
+        # generic shapes: the reference's formulation on torch ops
         combined = torch.cat((dense_features.unsqueeze(1), sparse_features), dim=1)
         interactions = torch.bmm(combined, combined.transpose(1, 2))
         flat = interactions[:, self.triu_indices[0], self.triu_indices[1]]
