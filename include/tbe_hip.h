@@ -57,6 +57,8 @@ extern "C" {
 #define TBE_OPT_EXACT_ADAGRAD 3
 #define TBE_OPT_DENSE_GRAD 100
 
+#define TBE_FLAG_UNIFORM_ALIGNED 1
+
 /* Hyper-parameters of the fused optimizer, passed by value. */
 typedef struct tbe_optimizer_args {
   int32_t optimizer;     /* TBE_OPT_* */
@@ -135,6 +137,9 @@ int tbe_forward_nobag_f32(const uint64_t* feat_weights, const int64_t* feat_rows
  *                    for SGD.
  * grad_out: same addressing as the forward output (feat_out_offset, grad_row_stride) when pooled,
  *           or [N, D] rows (grad_row_stride = D) for pooling_mode NONE.
+ * flags: TBE_FLAG_UNIFORM_ALIGNED = the host asserts that every feature has dim == max_D
+ *        (a multiple of 4) and that every table / state base, out offset and the gradient rows
+ *        are 16-B aligned; enables the specialised kernels.  0 is always correct.
  * workspace: at least tbe_backward_workspace_bytes(N, F, B, max_D, key_bits) bytes.
  * ---------------------------------------------------------------------------------- */
 size_t tbe_backward_workspace_bytes(int64_t N, int32_t F, int32_t B, int32_t max_D,
@@ -147,8 +152,9 @@ int tbe_backward_fused_f32(const uint64_t* feat_weights, const int32_t* feat_D,
                            int32_t max_D, int32_t key_bits, const int64_t* indices, int64_t N,
                            const int64_t* offsets, const float* per_sample_weights,
                            int32_t pooling_mode, const float* grad_out,
-                           int64_t grad_row_stride, tbe_optimizer_args opt, void* workspace,
-                           size_t workspace_bytes, int32_t* bounds_errors, void* stream);
+                           int64_t grad_row_stride, tbe_optimizer_args opt, int32_t flags,
+                           void* workspace, size_t workspace_bytes, int32_t* bounds_errors,
+                           void* stream);
 
 /* ------------------------------------------------------------------------------------
  * torch.ops.fbgemm.asynchronous_complete_cumsum (torchrec/sparse/jagged_tensor.py:35-36):

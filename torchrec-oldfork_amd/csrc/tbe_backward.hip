@@ -21,6 +21,7 @@
 //                 order and applies the update.
 // Fixed chunks keep the work balanced no matter how skewed the ids are (a 3-row table
 // receives B contributions per row).
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -61,6 +62,7 @@ struct BwdArgs {
   int32_t* origin_list;  // [nchunks] chunks whose last run continues (compacted, any order)
   int32_t* origin_count; // [1]
   int32_t max_D_pad;
+  int32_t fast_D;  // uniform feature dim when TBE_FLAG_UNIFORM_ALIGNED, else 0
   int32_t* bounds_errors;
 };
 
@@ -150,11 +152,12 @@ __device__ __forceinline__ float group_sum(float v) {
 
 // Applies the optimizer to one table row.  `g` = coalesced gradient columns held by this lane,
 // `w` = current weight columns (pre-loaded).  Group-uniform control flow.
-template <int G, int NV>
+// OPTC >= 0 fixes the optimizer at compile time (smaller live state => more waves per SIMD).
+template <int G, int NV, int OPTC = -1>
 __device__ __forceinline__ void apply_row(const BwdArgs& a, int f, int64_t local_row, int D,
                                           bool vec, int gl, float* wrow, float4 (&w)[NV],
                                           float4 (&g)[NV]) {
-  const int optimizer = a.opt.optimizer;
+  const int optimizer = OPTC >= 0 ? OPTC : a.opt.optimizer;
   const float lr = a.opt.learning_rate;
   if (optimizer == TBE_OPT_EXACT_SGD) {
 #pragma unroll
@@ -266,10 +269,11 @@ struct BwdUnroll {
   static constexpr int U = NV == 1 ? 4 : (NV == 2 ? 2 : 1);
 };
 
-template <typename KeyT, int G, int NV>
-__global__ __launch_bounds__(256) void bwd_update_kernel(BwdArgs a) {
+// FAST: every feature has dim a.fast_D (multiple of 4), SUM pooling, no per-sample weights, every
+// row base 16-B aligned (TBE_FLAG_UNIFORM_ALIGNED from the host) — the Criteo configuration.
+template <typename KeyT, int G, int NV, int OPTC, bool FAST, int U, int MINW>
+__global__ __launch_bounds__(256, MINW) void bwd_update_kernel(BwdArgs a) {
   constexpr int NG = kWave / G;
-  constexpr int U = BwdUnroll<NV>::U;
   const int lane = threadIdx.x & 63;
   const int g = lane / G;
   const int gl = lane % G;
@@ -320,18 +324,20 @@ __global__ __launch_bounds__(256) void bwd_update_kernel(BwdArgs a) {
     const uint32_t pos_k = static_cast<uint32_t>(pay_k);
     const int f_k = valid_k ? static_cast<int>(bag_k / static_cast<uint32_t>(a.B)) : 0;
     const int b_k = static_cast<int>(bag_k - static_cast<uint32_t>(f_k) * static_cast<uint32_t>(a.B));
-    const int D_k = a.feat_D[f_k];
+    const int D_k = FAST ? a.fast_D : a.feat_D[f_k];
     float w_k = 1.f;
     const float* gptr_k = a.grad_out;
     const float* wptr_k = nullptr;
     int64_t lrow_k = 0;
     if (valid_k) {
-      if (a.psw != nullptr) w_k = a.psw[pos_k];
-      if (mean) {
-        const int64_t len = a.offsets[bag_k + 1] - a.offsets[bag_k];
-        w_k = w_k / static_cast<float>(len);
+      if (!FAST) {
+        if (a.psw != nullptr) w_k = a.psw[pos_k];
+        if (mean) {
+          const int64_t len = a.offsets[bag_k + 1] - a.offsets[bag_k];
+          w_k = w_k / static_cast<float>(len);
+        }
       }
-      gptr_k = nobag ? a.grad_out + static_cast<int64_t>(pos_k) * a.grad_stride
+      gptr_k = (!FAST && nobag) ? a.grad_out + static_cast<int64_t>(pos_k) * a.grad_stride
                      : a.grad_out + static_cast<int64_t>(b_k) * a.grad_stride + a.feat_out_offset[f_k];
       lrow_k = static_cast<int64_t>(key_k) - a.feat_row_base[f_k];
       wptr_k = reinterpret_cast<const float*>(a.feat_weights[f_k]) + lrow_k * D_k;
@@ -356,14 +362,14 @@ __global__ __launch_bounds__(256) void bwd_update_kernel(BwdArgs a) {
         const bool inb = (j + u) < n;
         val[u] = inb && (__shfl(static_cast<int>(valid_k), src, kWave) != 0);
         lst[u] = inb && (__shfl(static_cast<int>(last_k), src, kWave) != 0);
-        wt[u] = __shfl(w_k, src, kWave);
+        wt[u] = FAST ? 1.f : __shfl(w_k, src, kWave);
         const float* gp = reinterpret_cast<const float*>(shflu64(reinterpret_cast<uint64_t>(gptr_k), src));
         wp[u] = reinterpret_cast<const float*>(shflu64(reinterpret_cast<uint64_t>(wptr_k), src));
-        Du[u] = __shfl(D_k, src, kWave);
+        Du[u] = FAST ? a.fast_D : __shfl(D_k, src, kWave);
         fu[u] = __shfl(f_k, src, kWave);
         lrow[u] = shfl64(lrow_k, src);
-        const bool gvec = ((Du[u] & 3) == 0) && ((reinterpret_cast<uintptr_t>(gp) & 15) == 0);
-        vecu[u] = ((Du[u] & 3) == 0) && ((reinterpret_cast<uintptr_t>(wp[u]) & 15) == 0);
+        const bool gvec = FAST || (((Du[u] & 3) == 0) && ((reinterpret_cast<uintptr_t>(gp) & 15) == 0));
+        vecu[u] = FAST || (((Du[u] & 3) == 0) && ((reinterpret_cast<uintptr_t>(wp[u]) & 15) == 0));
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
           const int d = (v * G + gl) * 4;
@@ -384,7 +390,7 @@ __global__ __launch_bounds__(256) void bwd_update_kernel(BwdArgs a) {
           tail_open = !lst[u];
           if (lst[u]) {
             if (started_here) {
-              apply_row<G, NV>(a, fu[u], lrow[u], Du[u], vecu[u], gl, const_cast<float*>(wp[u]), wr[u], acc);
+              apply_row<G, NV, OPTC>(a, fu[u], lrow[u], Du[u], vecu[u], gl, const_cast<float*>(wp[u]), wr[u], acc);
             } else {
               float* pf = a.partial_first + chunk * a.max_D_pad;
 #pragma unroll
@@ -591,6 +597,12 @@ __global__ __launch_bounds__(256) void bwd_fixup_kernel(BwdArgs a) {
 }
 
 static int pick_chunk(int64_t N) {
+  static const int forced = [] {
+    const char* e = getenv("TBE_BWD_CHUNK");  // tuning knob (multiple of 32 in [32, 1024])
+    const int v = e ? atoi(e) : 0;
+    return (v >= 32 && v <= 1024 && v % 32 == 0) ? v : 0;
+  }();
+  if (forced) return forced;
   int64_t c = (N + 16383) / 16384;
   c = (c + 31) / 32 * 32;
   if (c < 32) c = 32;
@@ -655,7 +667,29 @@ static int launch_update(const BwdArgs& a, hipStream_t st) {
   const unsigned grid = static_cast<unsigned>((nchunks + groups_per_block - 1) / groups_per_block);
   {
     ProfileSpan span(TBE_PROFILE_BWD_UPDATE_KERNEL, st);
-    hipLaunchKernelGGL((bwd_update_kernel<KeyT, G, NV>), dim3(grid), dim3(256), 0, st, a);
+    constexpr int UG = BwdUnroll<NV>::U;
+    static const int variant = [] {
+      const char* e = getenv("TBE_BWD_VARIANT");
+      return e ? atoi(e) : 0;
+    }();
+    const bool fast = a.fast_D > 0 && a.pooling_mode == TBE_POOL_SUM && a.psw == nullptr;
+    const int oc = a.opt.optimizer;
+#define TBE_UPD(OPTC, FAST_, UU, MW) \
+  hipLaunchKernelGGL((bwd_update_kernel<KeyT, G, NV, OPTC, FAST_, UU, MW>), dim3(grid), dim3(256), 0, st, a)
+    if (fast && G == 32 && NV == 1 && oc == TBE_OPT_EXACT_SGD) {
+      switch (variant) {
+        case 1: TBE_UPD(TBE_OPT_EXACT_SGD, true, 4, 8); break;
+        case 2: TBE_UPD(TBE_OPT_EXACT_SGD, true, 2, 8); break;
+        case 3: TBE_UPD(TBE_OPT_EXACT_SGD, true, 8, 4); break;
+        case 4: TBE_UPD(TBE_OPT_EXACT_SGD, true, 2, 4); break;
+        default: TBE_UPD(TBE_OPT_EXACT_SGD, true, 4, 4); break;
+      }
+    } else if (fast && G == 32 && NV == 1 && oc == TBE_OPT_EXACT_ROWWISE_ADAGRAD) {
+      TBE_UPD(TBE_OPT_EXACT_ROWWISE_ADAGRAD, true, 4, 4);
+    } else {
+      TBE_UPD(-1, false, UG, 1);
+    }
+#undef TBE_UPD
   }
   TBE_CHECK_LAUNCH("tbe_backward update");
   const unsigned fgrid = static_cast<unsigned>(std::min<int64_t>((nchunks + 3) / 4, 1024));
@@ -723,8 +757,8 @@ extern "C" int tbe_backward_fused_f32(
     const uint64_t* feat_state1, int32_t F, int32_t B, int32_t max_D,
     int32_t key_bits, const int64_t* indices, int64_t N, const int64_t* offsets,
     const float* per_sample_weights, int32_t pooling_mode, const float* grad_out,
-    int64_t grad_row_stride, tbe_optimizer_args opt, void* workspace, size_t workspace_bytes,
-    int32_t* bounds_errors, void* stream) {
+    int64_t grad_row_stride, tbe_optimizer_args opt, int32_t flags, void* workspace,
+    size_t workspace_bytes, int32_t* bounds_errors, void* stream) {
   TBE_REQUIRE(F > 0 && B >= 0 && N >= 0, "tbe_backward_fused_f32: bad sizes");
   TBE_REQUIRE(max_D > 0 && max_D <= 2048, "tbe_backward_fused_f32: max_D=%d outside (0, 2048]", max_D);
   TBE_REQUIRE(key_bits >= 1 && key_bits <= 64, "tbe_backward_fused_f32: key_bits=%d", key_bits);
@@ -791,6 +825,8 @@ extern "C" int tbe_backward_fused_f32(
   a.origin_list = w.origin_list;
   a.origin_count = w.origin_count;
   a.max_D_pad = (max_D + 3) / 4 * 4;
+  a.fast_D = ((flags & TBE_FLAG_UNIFORM_ALIGNED) && max_D % 4 == 0 && grad_row_stride % 4 == 0 &&
+              (reinterpret_cast<uintptr_t>(grad_out) & 15) == 0) ? max_D : 0;
   a.bounds_errors = bounds_errors;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (key_bits > 32) return run_backward<uint64_t>(a, w, max_D, st);

@@ -346,6 +346,10 @@ class _TBEBase(nn.Module):
         else:
             out_off, stride, _ = self._pooled_layout(B)
         feat_state0 = state0_override if state0_override is not None else lay.feat_state0
+        # TBE_FLAG_UNIFORM_ALIGNED: one dim for every feature, multiple of 4 (table bases are laid
+        # out 16-B aligned by _init_tables; out offsets are then multiples of 4 as well)
+        flags = 1 if (len(set(self.dims_per_table)) == 1 and self.max_D % 4 == 0 and stride % 4 == 0
+                      and state0_override is None) else 0
         with torch.cuda.device(dev):
             nbytes = lib.tbe_backward_workspace_bytes(N, self.F, B, self.max_D, self.key_bits)
             if nbytes == 0:
@@ -358,7 +362,7 @@ class _TBEBase(nn.Module):
                                            ptr(lay.feat_state1), self.F, B,
                                            self.max_D, self.key_bits, ptr(indices), N, ptr(offsets),
                                            ptr(per_sample_weights), int(self.pooling_mode),
-                                           ptr(grad_out), stride, opt, ptr(ws), ws.numel(),
+                                           ptr(grad_out), stride, opt, flags, ptr(ws), ws.numel(),
                                            ptr(self._errors()), stream_ptr(dev)),
                 "tbe_backward_fused_f32",
             )
