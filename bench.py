@@ -125,7 +125,7 @@ def main():
         pipe.progress(it)
     sync_all()
     lib.tbe_profile_enable(1)
-    for s in range(3):
+    for s in range(4):
         read_profile(lib, s)
     sync_all()
     t0 = time.perf_counter()
@@ -134,7 +134,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     lib.tbe_profile_enable(0)
-    prof = [read_profile(lib, s) for s in range(3)]
+    prof = [read_profile(lib, s) for s in range(4)]
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -151,13 +151,14 @@ def main():
     per_feat_bwd = D * 4 + 16 + 2 * D * 4
     kern = {}
     for name, slot, per_feat in (("tbe_fwd_short_kernel", 0, per_feat_fwd), ("bwd_update_kernel", 1, per_feat_bwd),
-                                 ("tbe_backward_total", 2, per_feat_bwd)):
+                                 ("tbe_backward_apply(update+fixup)", 2, per_feat_bwd),
+                                 ("tbe_backward_prepare(linearize+sort, side stream)", 3, per_feat_bwd)):
         tot_ms, n = prof[slot]
         if n:
             avg_ms = tot_ms / n
             kern[name] = {"avg_us": avg_ms * 1e3, "launches": n,
                           "GB/s": feat_units * per_feat * args.global_batch / (avg_ms * 1e-3) / 1e9}
-    dom = max((k for k in kern if k != "tbe_backward_total"), key=lambda k: kern[k]["avg_us"], default=None)
+    dom = max((k for k in kern if not k.startswith("tbe_backward_")), key=lambda k: kern[k]["avg_us"], default=None)
     roofline = None
     if dom:
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(kern[dom]["GB/s"], 1), "peak": HBM_PEAK_GBS,

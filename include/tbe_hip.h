@@ -79,8 +79,9 @@ int32_t tbe_abi_version(void);
  * launch count since the last read, and clears the slot.  Never enabled by the product path. */
 #define TBE_PROFILE_FWD_KERNEL 0        /* tbe_fwd_*_kernel, one launch per forward call */
 #define TBE_PROFILE_BWD_UPDATE_KERNEL 1 /* bwd_update_kernel, one launch per backward call */
-#define TBE_PROFILE_BWD_TOTAL 2         /* whole backward: linearize + sort + update + fix-up */
-#define TBE_PROFILE_NUM_SLOTS 3
+#define TBE_PROFILE_BWD_TOTAL 2         /* fused call: linearize + sort + update + fix-up; apply call: update + fix-up */
+#define TBE_PROFILE_BWD_PREPARE 3       /* linearize + sort (gradient independent) */
+#define TBE_PROFILE_NUM_SLOTS 4
 int tbe_profile_enable(int32_t on);
 int tbe_profile_read(int32_t slot, double* total_ms, int64_t* count);
 
@@ -155,6 +156,26 @@ int tbe_backward_fused_f32(const uint64_t* feat_weights, const int32_t* feat_D,
                            int64_t grad_row_stride, tbe_optimizer_args opt, int32_t flags,
                            void* workspace, size_t workspace_bytes, int32_t* bounds_errors,
                            void* stream);
+
+/* The backward in two phases, so that the gradient-independent half (linearize + stable sort of
+ * the batch's row keys) can be enqueued on a side stream right after the forward call and overlap
+ * the dense MLPs; `apply` then needs only update + fix-up once grad_out exists.
+ * tbe_backward_fused_f32 == prepare followed by apply on one stream.  `apply` must receive the
+ * workspace a `prepare` call filled for the same (indices, offsets, N, F, B, max_D, key_bits). */
+int tbe_backward_prepare(const int64_t* feat_rows, const int64_t* feat_row_base, int32_t F,
+                         int32_t B, int32_t max_D, int32_t key_bits, const int64_t* indices,
+                         int64_t N, const int64_t* offsets, int32_t pooling_mode,
+                         void* workspace, size_t workspace_bytes, int32_t* bounds_errors,
+                         void* stream);
+int tbe_backward_apply_f32(const uint64_t* feat_weights, const int32_t* feat_D,
+                           const int64_t* feat_out_offset, const int64_t* feat_rows,
+                           const int64_t* feat_row_base, const uint64_t* feat_state0,
+                           const uint64_t* feat_state1, int32_t F, int32_t B,
+                           int32_t max_D, int32_t key_bits, const int64_t* indices, int64_t N,
+                           const int64_t* offsets, const float* per_sample_weights,
+                           int32_t pooling_mode, const float* grad_out,
+                           int64_t grad_row_stride, tbe_optimizer_args opt, int32_t flags,
+                           void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * torch.ops.fbgemm.asynchronous_complete_cumsum (torchrec/sparse/jagged_tensor.py:35-36):

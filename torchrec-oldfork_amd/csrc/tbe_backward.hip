@@ -698,11 +698,18 @@ static int launch_update(const BwdArgs& a, hipStream_t st) {
   return TBE_OK;
 }
 
+constexpr int kPhasePrepare = 1;  // gradient-independent: linearize + sort
+constexpr int kPhaseApply = 2;    // update + fix-up
+
 template <typename KeyT>
-static int run_backward(BwdArgs a, const BwdWorkspace& w, int32_t max_D, hipStream_t st) {
-  ProfileSpan total_span(TBE_PROFILE_BWD_TOTAL, st);
+static int run_backward(BwdArgs a, const BwdWorkspace& w, int32_t max_D, hipStream_t st, int phase) {
+  ProfileSpan total_span(phase == kPhasePrepare ? -1 : TBE_PROFILE_BWD_TOTAL, st);
   KeyT* kin = static_cast<KeyT*>(w.keys_in);
   KeyT* kout = static_cast<KeyT*>(w.keys_out);
+  a.keys_sorted = kout;
+  a.payload_sorted = w.pay_out;
+  if (phase & kPhasePrepare) {
+  ProfileSpan prep_span(TBE_PROFILE_BWD_PREPARE, st);
   if (a.pooling_mode == TBE_POOL_NONE) {
     const size_t lds = (static_cast<size_t>(a.F) + 1) * sizeof(int64_t);
     const unsigned grid = static_cast<unsigned>(std::min<int64_t>((a.N + 255) / 256, 256 * 16));
@@ -727,8 +734,8 @@ static int run_backward(BwdArgs a, const BwdWorkspace& w, int32_t max_D, hipStre
     set_error("tbe_backward: radix sort failed: %s", hipGetErrorString(e));
     return TBE_ERR_LAUNCH;
   }
-  a.keys_sorted = kout;
-  a.payload_sorted = w.pay_out;
+  }  // prepare
+  if (!(phase & kPhaseApply)) return TBE_OK;
   if (max_D <= 64) return launch_update<KeyT, 16, 1>(a, st);
   if (max_D <= 128) return launch_update<KeyT, 32, 1>(a, st);
   if (max_D <= 256) return launch_update<KeyT, 64, 1>(a, st);
@@ -751,15 +758,19 @@ extern "C" size_t tbe_backward_workspace_bytes(int64_t N, int32_t F, int32_t B, 
   return w.total;
 }
 
-extern "C" int tbe_backward_fused_f32(
+static int backward_entry(
     const uint64_t* feat_weights, const int32_t* feat_D, const int64_t* feat_out_offset,
     const int64_t* feat_rows, const int64_t* feat_row_base, const uint64_t* feat_state0,
     const uint64_t* feat_state1, int32_t F, int32_t B, int32_t max_D,
     int32_t key_bits, const int64_t* indices, int64_t N, const int64_t* offsets,
     const float* per_sample_weights, int32_t pooling_mode, const float* grad_out,
     int64_t grad_row_stride, tbe_optimizer_args opt, int32_t flags, void* workspace,
-    size_t workspace_bytes, int32_t* bounds_errors, void* stream) {
+    size_t workspace_bytes, int32_t* bounds_errors, void* stream, int phase) {
   TBE_REQUIRE(F > 0 && B >= 0 && N >= 0, "tbe_backward_fused_f32: bad sizes");
+  if (phase == kPhasePrepare) {  // gradient / optimizer arguments are not used by this phase
+    grad_row_stride = 1;
+    opt.optimizer = TBE_OPT_EXACT_SGD;
+  }
   TBE_REQUIRE(max_D > 0 && max_D <= 2048, "tbe_backward_fused_f32: max_D=%d outside (0, 2048]", max_D);
   TBE_REQUIRE(key_bits >= 1 && key_bits <= 64, "tbe_backward_fused_f32: key_bits=%d", key_bits);
   TBE_REQUIRE(pooling_mode == TBE_POOL_SUM || pooling_mode == TBE_POOL_MEAN || pooling_mode == TBE_POOL_NONE,
@@ -784,8 +795,9 @@ extern "C" int tbe_backward_fused_f32(
       return TBE_ERR_UNSUPPORTED;
   }
   if (N == 0 || B == 0) return TBE_OK;
-  TBE_REQUIRE(feat_weights && feat_D && feat_out_offset && feat_rows && feat_row_base && indices && offsets && grad_out && workspace,
-              "tbe_backward_fused_f32: null pointer");
+  TBE_REQUIRE(feat_rows && feat_row_base && indices && offsets && workspace, "tbe_backward: null pointer");
+  if (phase & kPhaseApply)
+    TBE_REQUIRE(feat_weights && feat_D && feat_out_offset && grad_out, "tbe_backward_fused_f32: null pointer");
   TBE_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "tbe_backward_fused_f32: workspace must be 256-B aligned");
   BwdWorkspace w;
   int rc = carve(workspace, N, max_D, key_bits, &w);
@@ -829,6 +841,43 @@ extern "C" int tbe_backward_fused_f32(
               (reinterpret_cast<uintptr_t>(grad_out) & 15) == 0) ? max_D : 0;
   a.bounds_errors = bounds_errors;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (key_bits > 32) return run_backward<uint64_t>(a, w, max_D, st);
-  return run_backward<uint32_t>(a, w, max_D, st);
+  if (key_bits > 32) return run_backward<uint64_t>(a, w, max_D, st, phase);
+  return run_backward<uint32_t>(a, w, max_D, st, phase);
+}
+
+extern "C" int tbe_backward_fused_f32(
+    const uint64_t* feat_weights, const int32_t* feat_D, const int64_t* feat_out_offset,
+    const int64_t* feat_rows, const int64_t* feat_row_base, const uint64_t* feat_state0,
+    const uint64_t* feat_state1, int32_t F, int32_t B, int32_t max_D,
+    int32_t key_bits, const int64_t* indices, int64_t N, const int64_t* offsets,
+    const float* per_sample_weights, int32_t pooling_mode, const float* grad_out,
+    int64_t grad_row_stride, tbe_optimizer_args opt, int32_t flags, void* workspace,
+    size_t workspace_bytes, int32_t* bounds_errors, void* stream) {
+  return backward_entry(feat_weights, feat_D, feat_out_offset, feat_rows, feat_row_base, feat_state0, feat_state1, F,
+                        B, max_D, key_bits, indices, N, offsets, per_sample_weights, pooling_mode, grad_out,
+                        grad_row_stride, opt, flags, workspace, workspace_bytes, bounds_errors, stream,
+                        kPhasePrepare | kPhaseApply);
+}
+
+extern "C" int tbe_backward_prepare(const int64_t* feat_rows, const int64_t* feat_row_base, int32_t F, int32_t B,
+                                    int32_t max_D, int32_t key_bits, const int64_t* indices, int64_t N,
+                                    const int64_t* offsets, int32_t pooling_mode, void* workspace,
+                                    size_t workspace_bytes, int32_t* bounds_errors, void* stream) {
+  tbe_optimizer_args opt{};
+  return backward_entry(nullptr, nullptr, nullptr, feat_rows, feat_row_base, nullptr, nullptr, F, B, max_D, key_bits,
+                        indices, N, offsets, nullptr, pooling_mode, nullptr, 1, opt, 0, workspace, workspace_bytes,
+                        bounds_errors, stream, kPhasePrepare);
+}
+
+extern "C" int tbe_backward_apply_f32(
+    const uint64_t* feat_weights, const int32_t* feat_D, const int64_t* feat_out_offset,
+    const int64_t* feat_rows, const int64_t* feat_row_base, const uint64_t* feat_state0,
+    const uint64_t* feat_state1, int32_t F, int32_t B, int32_t max_D,
+    int32_t key_bits, const int64_t* indices, int64_t N, const int64_t* offsets,
+    const float* per_sample_weights, int32_t pooling_mode, const float* grad_out,
+    int64_t grad_row_stride, tbe_optimizer_args opt, int32_t flags, void* workspace,
+    size_t workspace_bytes, void* stream) {
+  return backward_entry(feat_weights, feat_D, feat_out_offset, feat_rows, feat_row_base, feat_state0, feat_state1, F,
+                        B, max_D, key_bits, indices, N, offsets, per_sample_weights, pooling_mode, grad_out,
+                        grad_row_stride, opt, flags, workspace, workspace_bytes, nullptr, stream, kPhaseApply);
 }

@@ -58,6 +58,17 @@ SIGNATURES = {
          c_i32, c_i32, c_void_p, c_i64, c_void_p, c_void_p, c_i32, c_void_p, c_i64, OptimizerArgs,
          c_i32, c_void_p, c_size, c_void_p, c_void_p],
     ),
+    "tbe_backward_prepare": (
+        ctypes.c_int,
+        [c_void_p, c_void_p, c_i32, c_i32, c_i32, c_i32, c_void_p, c_i64, c_void_p, c_i32, c_void_p,
+         c_size, c_void_p, c_void_p],
+    ),
+    "tbe_backward_apply_f32": (
+        ctypes.c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32,
+         c_i32, c_i32, c_void_p, c_i64, c_void_p, c_void_p, c_i32, c_void_p, c_i64, OptimizerArgs,
+         c_i32, c_void_p, c_size, c_void_p],
+    ),
     "tbe_cumsum_workspace_bytes": (c_size, [c_i64]),
     "tbe_cumsum": (ctypes.c_int, [c_void_p, c_void_p, c_i64, c_i32, c_i32, c_void_p, c_size, c_void_p]),
     "tbe_permute_2d_workspace_bytes": (c_size, [c_i32, c_i32, c_i32]),

@@ -185,6 +185,9 @@ class _TBEBase(nn.Module):
         self._row_sizes = row_sizes
         self._layout = _Layout()
         self._bounds_errors: Optional[torch.Tensor] = None
+        self._side_stream = None
+        # sort the batch's row keys on a side stream during forward (see _prepare_backward)
+        self.overlap_backward_sort = True
 
     # -- storage helpers ------------------------------------------------------------------
     def _alloc(self, placement: str, numel: int) -> torch.Tensor:
@@ -330,8 +333,41 @@ class _TBEBase(nn.Module):
             )
         return out
 
+    def _prepare_backward(self, indices, offsets, B: int):
+        """Enqueues the gradient-independent half of backward (linearize + stable sort of the row
+        keys) on a side stream, right after the forward kernel, so that it overlaps whatever the
+        caller does between forward and backward (the dense MLPs).  Returns (workspace, event)."""
+        N = indices.numel()
+        if N == 0 or B == 0:
+            return None
+        lay = self._get_layout()
+        dev = self.current_device
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            nbytes = lib.tbe_backward_workspace_bytes(N, self.F, B, self.max_D, self.key_bits)
+            if nbytes == 0:
+                check(-2, "tbe_backward_workspace_bytes")
+            ws = workspace(nbytes, dev)
+            side = self._side_stream
+            if side is None or side.device != dev:
+                side = self._side_stream = torch.cuda.Stream(dev)
+            cur = torch.cuda.current_stream(dev)
+            side.wait_stream(cur)
+            for t in (ws, indices, offsets):
+                t.record_stream(side)
+            check(
+                lib.tbe_backward_prepare(ptr(lay.feat_rows), ptr(lay.feat_row_base), self.F, B, self.max_D,
+                                         self.key_bits, ptr(indices), N, ptr(offsets), int(self.pooling_mode),
+                                         ptr(ws), ws.numel(), ptr(self._errors()), side.cuda_stream),
+                "tbe_backward_prepare",
+            )
+            ev = torch.cuda.Event()
+            ev.record(side)
+        return ws, ev
+
     def _backward_impl(self, grad_out, indices, offsets, per_sample_weights, B: int,
-                       opt: OptimizerArgs, state0_override: Optional[torch.Tensor] = None) -> None:
+                       opt: OptimizerArgs, state0_override: Optional[torch.Tensor] = None,
+                       prepared=None) -> None:
         lay = self._get_layout()
         dev = self.current_device
         lib = _lib.load()
@@ -351,6 +387,19 @@ class _TBEBase(nn.Module):
         flags = 1 if (len(set(self.dims_per_table)) == 1 and self.max_D % 4 == 0 and stride % 4 == 0
                       and state0_override is None) else 0
         with torch.cuda.device(dev):
+            if prepared is not None:
+                ws, ev = prepared
+                torch.cuda.current_stream(dev).wait_event(ev)
+                check(
+                    lib.tbe_backward_apply_f32(ptr(lay.feat_weights), ptr(lay.feat_D), ptr(out_off),
+                                               ptr(lay.feat_rows), ptr(lay.feat_row_base), ptr(feat_state0),
+                                               ptr(lay.feat_state1), self.F, B, self.max_D, self.key_bits,
+                                               ptr(indices), N, ptr(offsets), ptr(per_sample_weights),
+                                               int(self.pooling_mode), ptr(grad_out), stride, opt, flags,
+                                               ptr(ws), ws.numel(), stream_ptr(dev)),
+                    "tbe_backward_apply_f32",
+                )
+                return
             nbytes = lib.tbe_backward_workspace_bytes(N, self.F, B, self.max_D, self.key_bits)
             if nbytes == 0:
                 check(-2, "tbe_backward_workspace_bytes")
@@ -372,19 +421,23 @@ class _FusedLookup(torch.autograd.Function):
     """forward = TBE gather/pool; backward = coalesce + fused optimizer (no weight grad)."""
 
     @staticmethod
-    def forward(ctx, placeholder, module, indices, offsets, per_sample_weights, B):
+    def forward(ctx, placeholder, module, indices, offsets, per_sample_weights, B, prepare):
         ctx.module = module
         ctx.B = B
         ctx.save_for_backward(indices, offsets, per_sample_weights)
-        return module._forward_impl(indices, offsets, per_sample_weights, B)
+        out = module._forward_impl(indices, offsets, per_sample_weights, B)
+        ctx.prepared = module._prepare_backward(indices, offsets, B) if prepare else None
+        return out
 
     @staticmethod
     def backward(ctx, grad_out):
         indices, offsets, psw = ctx.saved_tensors
         module = ctx.module
         module.iter += 1
-        module._backward_impl(grad_out, indices, offsets, psw, ctx.B, module._optimizer_struct())
-        return None, None, None, None, None, None
+        module._backward_impl(grad_out, indices, offsets, psw, ctx.B, module._optimizer_struct(),
+                              prepared=ctx.prepared)
+        ctx.prepared = None
+        return None, None, None, None, None, None, None
 
 
 class SplitTableBatchedEmbeddingBagsCodegen(_TBEBase):
@@ -536,8 +589,9 @@ class SplitTableBatchedEmbeddingBagsCodegen(_TBEBase):
                 per_sample_weights: Optional[torch.Tensor] = None,
                 feature_requires_grad: Optional[torch.Tensor] = None) -> torch.Tensor:
         indices, offsets, per_sample_weights, B = self._check_inputs(indices, offsets, per_sample_weights)
+        prepare = self.overlap_backward_sort and torch.is_grad_enabled()
         return _FusedLookup.apply(self.placeholder_autograd_tensor, self, indices, offsets,
-                                  per_sample_weights, B)
+                                  per_sample_weights, B, prepare)
 
 
 class _DenseLookup(torch.autograd.Function):
