@@ -147,23 +147,46 @@ def main():
     shard = model.sharded_modules()[0]
     feat_units = sum((1.0 / world) if shard._table_kind[i] < 0 else (1.0 if shard._table_kind[i] == rank else 0.0)
                      for i in range(F))
-    per_feat_fwd = D * 4 + 8 + 8 + D * 4
-    per_feat_bwd = D * 4 + 16 + 2 * D * 4
+    # Algorithmic bytes per launch (SURVEY.md §8d general formula, L = 1, fp32 rows, int64 ids):
+    #   forward : units * B * (D*4 row + 8 id + 8 offset + D*4 output)
+    #   backward: units * B * (D*4 grad + 16 ids) + U_launch * 2*D*4   (row read + row write per DISTINCT row)
+    # U_launch = distinct table rows the batch touches, counted by the kernel itself
+    # (tbe_profile_read_rows).  Uniform ids over the Criteo table sizes hit the 11 tiny tables
+    # thousands of times per row, so U is ~10 rows/sample, not F*L = 26: pricing the backward at
+    # F*L rows would credit the kernel with bytes it never moves (it did read > 100 % of peak that way).
+    rows_upd = ctypes.c_int64(0)
+    lib.tbe_profile_read_rows(ctypes.byref(rows_upd))
+    n_bwd = max(prof[1][1], 1)
+    U_launch = rows_upd.value / n_bwd
+    fwd_bytes = feat_units * args.global_batch * (D * 4 + 8 + 8 + D * 4)
+    bwd_bytes = feat_units * args.global_batch * (D * 4 + 16) + U_launch * 2 * D * 4
+    bwd_bytes_all_distinct = feat_units * args.global_batch * (D * 4 + 16 + 2 * D * 4)
     kern = {}
-    for name, slot, per_feat in (("tbe_fwd_short_kernel", 0, per_feat_fwd), ("bwd_update_kernel", 1, per_feat_bwd),
-                                 ("tbe_backward_apply(update+fixup)", 2, per_feat_bwd),
-                                 ("tbe_backward_prepare(linearize+sort, side stream)", 3, per_feat_bwd)):
+    for name, slot, nbytes in (("tbe_fwd_short_kernel", 0, fwd_bytes), ("bwd_update_kernel", 1, bwd_bytes),
+                               ("tbe_backward_apply(update+fixup)", 2, bwd_bytes),
+                               ("tbe_backward_prepare(linearize+sort, side stream)", 3, 0.0)):
         tot_ms, n = prof[slot]
         if n:
             avg_ms = tot_ms / n
-            kern[name] = {"avg_us": avg_ms * 1e3, "launches": n,
-                          "GB/s": feat_units * per_feat * args.global_batch / (avg_ms * 1e-3) / 1e9}
+            kern[name] = {"avg_us": avg_ms * 1e3, "launches": n, "algorithmic_MB": nbytes / 1e6,
+                          "GB/s": nbytes / (avg_ms * 1e-3) / 1e9}
     dom = max((k for k in kern if not k.startswith("tbe_backward_")), key=lambda k: kern[k]["avg_us"], default=None)
     roofline = None
     if dom:
+        # PMC traffic (FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction) measured by a separate rocprofv3
+        # --pmc run of the same kernels (profiles/r01_pmc_traffic.json); only valid for the N = 1 shape.
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if world == 1 and args.global_batch == 65536 and not args.zipf and os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path))
+            hit = [v for k, v in pmc.items() if dom.split("(")[0] in k]
+            if hit:
+                traffic = hit[0]["hbm_total_MB"] * 1e6
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(kern[dom]["GB/s"], 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(kern[dom]["GB/s"] / HBM_PEAK_GBS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(kern[dom]["GB/s"] / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "avg_launch_us": round(kern[dom]["avg_us"], 1),
+                    "distinct_rows_per_sample": round(U_launch / args.global_batch, 2),
+                    "bwd_MB_if_all_rows_distinct": round(bwd_bytes_all_distinct / 1e6, 1),
                     "all": {k: {kk: round(vv, 1) for kk, vv in v.items()} for k, v in kern.items()}}
 
     cpu = None
@@ -182,7 +205,10 @@ def main():
             "metric": "samples/sec Criteo-1TB DLRM batch 65536", "value": round(value, 1), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            # the reference's only published number is 5 497 159.68 samples/s on 8 x A100-40GB
+            # (examples/dlrm/README.MD:45, real Criteo data, end to end) — comparable at N = 8 only
+            "vs_baseline": round(value / 5497159.68, 3) if world == 8 else None,
+            "dtype": "f32", "data": "synthetic",
             "config": {"workload": "DLRM Criteo-1TB shape: 26 tables (177.9M rows, 84.85 GiB fp32, D=128), 13 dense, "
                                    "pooling factor 1, dense 512-256-128, over 1024-1024-512-256-1, fused exact SGD",
                        "global_batch": args.global_batch, "local_batch": B_local,

@@ -84,6 +84,9 @@ int32_t tbe_abi_version(void);
 #define TBE_PROFILE_NUM_SLOTS 4
 int tbe_profile_enable(int32_t on);
 int tbe_profile_read(int32_t slot, double* total_ms, int64_t* count);
+/* table rows updated by backward launches since the last read (distinct rows per batch = the U of
+ * SURVEY.md §8d's byte formula); synchronises the device. */
+int tbe_profile_read_rows(int64_t* rows_updated);
 
 /* ------------------------------------------------------------------------------------
  * TBE forward (pooled): replaces SplitTableBatchedEmbeddingBagsCodegen.__call__ /

@@ -20,6 +20,9 @@ static std::vector<Span> g_spans[TBE_PROFILE_NUM_SLOTS];
 
 bool profile_enabled() { return g_on; }
 
+static unsigned long long* g_rows_dev = nullptr;
+unsigned long long* profile_unique_rows_counter() { return g_on ? g_rows_dev : nullptr; }
+
 // Returns an event to record before the launch (and registers its partner, returned via *after).
 void profile_begin(int slot, hipStream_t st, hipEvent_t* after) {
   *after = nullptr;
@@ -47,6 +50,10 @@ void profile_end(hipEvent_t after, hipStream_t st) {
 
 extern "C" int tbe_profile_enable(int32_t on) {
   std::lock_guard<std::mutex> lk(tbe::g_mu);
+  if (on && tbe::g_rows_dev == nullptr) {
+    if (hipMalloc(&tbe::g_rows_dev, sizeof(unsigned long long)) != hipSuccess) return TBE_ERR_LAUNCH;
+    (void)hipMemset(tbe::g_rows_dev, 0, sizeof(unsigned long long));
+  }
   tbe::g_on = on != 0;
   return TBE_OK;
 }
@@ -71,5 +78,17 @@ extern "C" int tbe_profile_read(int32_t slot, double* total_ms, int64_t* count) 
   }
   *total_ms = tot;
   *count = n;
+  return TBE_OK;
+}
+
+extern "C" int tbe_profile_read_rows(int64_t* rows_updated) {
+  if (!rows_updated) return TBE_ERR_INVALID_ARGUMENT;
+  *rows_updated = 0;
+  if (tbe::g_rows_dev == nullptr) return TBE_OK;
+  unsigned long long v = 0;
+  if (hipDeviceSynchronize() != hipSuccess) return TBE_ERR_LAUNCH;
+  if (hipMemcpy(&v, tbe::g_rows_dev, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return TBE_ERR_LAUNCH;
+  (void)hipMemset(tbe::g_rows_dev, 0, sizeof(v));
+  *rows_updated = static_cast<int64_t>(v);
   return TBE_OK;
 }

@@ -64,6 +64,7 @@ struct BwdArgs {
   int32_t max_D_pad;
   int32_t fast_D;  // uniform feature dim when TBE_FLAG_UNIFORM_ALIGNED, else 0
   int32_t* bounds_errors;
+  unsigned long long* unique_rows;  // optional profiling counter: table rows updated
 };
 
 template <typename KeyT>
@@ -296,6 +297,7 @@ __global__ __launch_bounds__(256, MINW) void bwd_update_kernel(BwdArgs a) {
   bool started_here = true;
   if (active && i0 > 0) started_here = skey[i0 - 1] != skey[i0];
   bool tail_open = false;  // last processed contribution did not end its run
+  int nrows = 0;           // table rows this group finished (profiling counter)
 
   float4 acc[NV];
 #pragma unroll
@@ -390,6 +392,7 @@ __global__ __launch_bounds__(256, MINW) void bwd_update_kernel(BwdArgs a) {
           tail_open = !lst[u];
           if (lst[u]) {
             if (started_here) {
+              ++nrows;
               apply_row<G, NV, OPTC>(a, fu[u], lrow[u], Du[u], vecu[u], gl, const_cast<float*>(wp[u]), wr[u], acc);
             } else {
               float* pf = a.partial_first + chunk * a.max_D_pad;
@@ -419,6 +422,8 @@ __global__ __launch_bounds__(256, MINW) void bwd_update_kernel(BwdArgs a) {
       }
     }
     if (gl == 0 && is_origin) a.origin_list[atomicAdd(a.origin_count, 1)] = static_cast<int32_t>(chunk);
+    nrows += is_origin;
+    if (a.unique_rows != nullptr && gl == 0 && nrows > 0) atomicAdd(a.unique_rows, static_cast<unsigned long long>(nrows));
   }
 }
 
@@ -840,6 +845,7 @@ static int backward_entry(
   a.fast_D = ((flags & TBE_FLAG_UNIFORM_ALIGNED) && max_D % 4 == 0 && grad_row_stride % 4 == 0 &&
               (reinterpret_cast<uintptr_t>(grad_out) & 15) == 0) ? max_D : 0;
   a.bounds_errors = bounds_errors;
+  a.unique_rows = (phase & kPhaseApply) ? profile_unique_rows_counter() : nullptr;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (key_bits > 32) return run_backward<uint64_t>(a, w, max_D, st, phase);
   return run_backward<uint32_t>(a, w, max_D, st, phase);

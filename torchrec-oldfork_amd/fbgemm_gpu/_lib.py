@@ -41,6 +41,7 @@ SIGNATURES = {
     "tbe_abi_version": (c_i32, []),
     "tbe_profile_enable": (ctypes.c_int, [c_i32]),
     "tbe_profile_read": (ctypes.c_int, [c_i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]),
+    "tbe_profile_read_rows": (ctypes.c_int, [ctypes.POINTER(c_i64)]),
     "tbe_forward_pooled_f32": (
         ctypes.c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p, c_i64,
