@@ -60,6 +60,14 @@ def _x_pack(grad, feat_out_col, feat_src, feat_slab_col, slab_offset, slab_strid
                                                    grad.shape[0], True, scale, numel))
 
 
+def _s_unpack(recv, dims, B_local, D_total, vec, scale):
+    return torch.from_numpy(oracle.a2a_pooled_unpack(recv.numpy(), dims.numpy(), B_local, scale))
+
+
+def _s_pack(grad, dims, vec, scale):
+    return torch.from_numpy(oracle.a2a_pooled_pack(grad.contiguous().numpy(), dims.numpy(), scale))
+
+
 def register() -> None:
     global _registered
     if _registered:
@@ -73,4 +81,6 @@ def register() -> None:
     _lib.impl("jagged_2d_to_dense", _jagged_2d_to_dense)
     _lib2.impl("pooled_exchange_unpack", _x_unpack)
     _lib2.impl("pooled_exchange_pack", _x_pack)
+    _lib2.impl("a2a_pooled_unpack", _s_unpack)
+    _lib2.impl("a2a_pooled_pack", _s_pack)
     _registered = True

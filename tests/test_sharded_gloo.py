@@ -155,3 +155,73 @@ def test_planner_balances_criteo_over_8_ranks():
         assert max(mem) < 288e9 * 0.85
     # rw_shard_rows examples of planner/enumerators.py:277-312
     assert rw_shard_rows(10, 3) == [4, 4, 2] and rw_shard_rows(5, 4) == [2, 2, 1, 0]
+
+
+def _e2e_worker(rank, W, port, ret):
+    """Full DLRM train steps through DistributedModelParallel + DDP + TrainPipelineSparseDist on
+    gloo/CPU with the oracle TBE (tests/_oracle_tbe.py)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=W)
+    try:
+        import _cpu_ops
+        _cpu_ops.register()
+        from _oracle_tbe import oracle_tbe_factory
+        from torchrec_amd.datasets.random import RandomRecDataset
+        from torchrec_amd.distributed.embeddingbag import EmbeddingBagCollectionSharder
+        from torchrec_amd.distributed.model_parallel import DistributedModelParallel
+        from torchrec_amd.distributed.train_pipeline import TrainPipelineSparseDist
+        from torchrec_amd.distributed.types import ShardingEnv
+        from torchrec_amd.models.dlrm import DLRMTrain
+        from torchrec_amd.modules.embedding_configs import EmbeddingBagConfig
+        from torchrec_amd.modules.embedding_modules import EmbeddingBagCollection
+        from torchrec_amd.optim.keyed import CombinedOptimizer, KeyedOptimizerWrapper
+
+        torch.manual_seed(0)  # same dense init on every rank (DDP also broadcasts rank 0's)
+        rows = [50, 9, 31, 17, 8]
+        D = 8
+        keys = [f"c{i}" for i in range(len(rows))]
+        tables = [EmbeddingBagConfig(name=f"t{i}", embedding_dim=D, num_embeddings=rows[i], feature_names=[keys[i]])
+                  for i in range(len(rows))]
+        ebc = EmbeddingBagCollection(tables, device=torch.device("meta"))
+        dev = torch.device("cpu")
+        train_model = DLRMTrain(ebc, dense_in_features=13, dense_arch_layer_sizes=[16, D], over_arch_layer_sizes=[12, 1],
+                                dense_device=dev)
+        env = ShardingEnv.from_process_group(dist.group.WORLD)
+        model = DistributedModelParallel(train_model, env=env, device=dev,
+                                         sharders=[EmbeddingBagCollectionSharder({"learning_rate": 0.05}, oracle_tbe_factory)])
+        opt = CombinedOptimizer([model.fused_optimizer,
+                                 KeyedOptimizerWrapper(dict(model.named_parameters()), lambda p: torch.optim.SGD(p, lr=0.05))])
+        data = RandomRecDataset(keys, 4, rows, manual_seed=100 + rank, num_generated_batches=3, num_batches=5, device=dev)
+        pipe = TrainPipelineSparseDist(model, opt, dev)
+        model.train()
+        it = iter(data)
+        losses = []
+        for _ in range(4):
+            loss, _ = pipe.progress(it)
+            losses.append(float(loss))
+        dense_sd = {k: v.detach().clone() for k, v in model.named_parameters()}
+        shards = {n: (w.clone().numpy(), r0) for n, (w, r0) in model.sharded_modules()[0].local_shards().items()}
+        ret[rank] = (losses, {k: v.numpy() for k, v in dense_sd.items()}, shards)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dlrm_e2e_dmp_ddp_pipeline_world2():
+    W = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_e2e_worker, args=(W, _free_port(), ret), nprocs=W, join=True)
+    l0, d0, s0 = ret[0]
+    l1, d1, s1 = ret[1]
+    assert all(np.isfinite(l0)) and all(np.isfinite(l1))
+    # DDP keeps the dense replicas identical
+    for k in d0:
+        np.testing.assert_allclose(d0[k], d1[k], rtol=0, atol=0)
+    # every table row lives on exactly one rank
+    rows = {"t0": 50, "t1": 9, "t2": 31, "t3": 17, "t4": 8}
+    seen = {k: 0 for k in rows}
+    for s in (s0, s1):
+        for n, (w, _) in s.items():
+            seen[n] += w.shape[0]
+    assert seen == rows

@@ -303,3 +303,38 @@ def test_a2a_ready_output_layout_matches_standard_layout():
     torch.cuda.synchronize()
     for wa, wb in zip(mod_a.split_embedding_weights(), mod_b.split_embedding_weights()):
         assert torch.equal(wa, wb)
+
+
+def test_managed_location_host_mapped_tables_match_device_tables():
+    """EmbeddingLocation.MANAGED (the reference's BATCHED_FUSED_UVM kernels,
+    torchrec/distributed/embedding_types.py:57-76): tables live in pinned host memory mapped into the
+    GPU; the same kernels must give the same forward output and the same updated rows."""
+    from fbgemm_gpu.split_embedding_configs import EmbOptimType
+    from fbgemm_gpu.split_table_batched_embeddings_ops import (
+        ComputeDevice, EmbeddingLocation, SplitTableBatchedEmbeddingBagsCodegen)
+
+    rng = np.random.default_rng(21)
+    rows, dims = [300, 41, 7], [128, 128, 128]
+    locs = [EmbeddingLocation.MANAGED, EmbeddingLocation.DEVICE, EmbeddingLocation.MANAGED_CACHING]
+    mod = SplitTableBatchedEmbeddingBagsCodegen(
+        [(r, d, loc, ComputeDevice.CUDA) for r, d, loc in zip(rows, dims, locs)], device=torch.device("cuda", 0),
+        optimizer=EmbOptimType.EXACT_ROWWISE_ADAGRAD, learning_rate=0.1, eps=1e-3)
+    tabs = oracle.Tables(rows, dims)
+    for t, w in enumerate(mod.split_embedding_weights()):
+        init = rng.standard_normal((rows[t], dims[t])).astype(np.float32)
+        tabs.weights[t][...] = init
+        w.copy_(torch.from_numpy(init))
+    assert not mod.split_embedding_weights()[0].is_cuda and mod.split_embedding_weights()[1].is_cuda
+    indices, offsets, _ = make_inputs(rng, rows, 64, 3)
+    out = mod(to_dev(indices), to_dev(offsets))
+    ref, _ = oracle.tbe_forward(tabs, indices, offsets)
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), ref)
+    grad = rng.standard_normal(tuple(out.shape)).astype(np.float32)
+    out.backward(to_dev(grad))
+    torch.cuda.synchronize()
+    s0 = [np.zeros(r, dtype=np.float32) for r in rows]
+    oracle.tbe_backward(tabs, indices, offsets, grad, oracle.OPT_EXACT_ROWWISE_ADAGRAD, 0.1, eps=1e-3, state0=s0)
+    for t, w in enumerate(mod.split_embedding_weights()):
+        np.testing.assert_allclose(w.cpu().numpy(), tabs.weights[t], rtol=2e-5, atol=2e-5)
+    for t, st in enumerate(mod.split_optimizer_states()):
+        np.testing.assert_allclose(st[0].cpu().numpy(), s0[t], rtol=2e-5, atol=2e-5)

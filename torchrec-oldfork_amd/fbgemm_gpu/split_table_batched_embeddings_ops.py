@@ -519,10 +519,13 @@ class SplitTableBatchedEmbeddingBagsCodegen(_TBEBase):
                 if needed:
                     n = self._row_sizes[p] if rowwise else self._flat_sizes[p]
                 self.register_buffer(f"{name}_{p}", self._alloc(p, n), persistent=False)
-        # fbgemm idiom: a zero-size parameter so autograd reaches backward
-        self.placeholder_autograd_tensor = nn.Parameter(
-            torch.zeros(0, dtype=torch.float32,
-                        device=self.current_device if self.current_device.type != "meta" else "meta"))
+        # A zero-size leaf that requires grad so autograd reaches backward.  Deliberately NOT an
+        # nn.Parameter: it must stay invisible to DistributedDataParallel and to dense optimizers
+        # (the reference hides its counterpart with `named_parameters -> ()`,
+        # batched_embedding_kernel.py:655-658).
+        object.__setattr__(self, "placeholder_autograd_tensor", torch.zeros(
+            0, dtype=torch.float32, requires_grad=True,
+            device=self.current_device if self.current_device.type != "meta" else "meta"))
 
     # storage ------------------------------------------------------------------------------
     def _flat_weights(self, placement: str) -> torch.Tensor:

@@ -11,7 +11,31 @@ _def.define("pooled_exchange_unpack(Tensor recv, Tensor feat_out_col, Tensor fea
             "Tensor slab_offset, Tensor slab_stride, int B_local, int D_total, bool vec, float scale) -> Tensor")
 _def.define("pooled_exchange_pack(Tensor grad, Tensor feat_out_col, Tensor feat_src, Tensor feat_slab_col, "
             "Tensor slab_offset, Tensor slab_stride, int numel, bool vec, float scale) -> Tensor")
+_def.define("a2a_pooled_unpack(Tensor recv, Tensor dim_sum_per_rank, int B_local, int D_total, bool vec, float scale) -> Tensor")
+_def.define("a2a_pooled_pack(Tensor grad, Tensor dim_sum_per_rank, bool vec, float scale) -> Tensor")
 _impl = torch.library.Library("tbe_hip", "IMPL", "CUDA")
+
+
+def _simple_unpack(recv, dims, B_local, D_total, vec, scale):
+    dev = require_gpu(recv, dims)
+    recv = recv.contiguous()
+    out = torch.empty((B_local, D_total), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().tbe_a2a_pooled_unpack(ptr(recv), ptr(out), ptr(dims), dims.numel(), B_local, D_total,
+                                                int(vec), scale, stream_ptr(dev)), "tbe_a2a_pooled_unpack")
+    return out
+
+
+def _simple_pack(grad, dims, vec, scale):
+    dev = require_gpu(grad, dims)
+    grad = grad.contiguous()
+    B_local, D_total = grad.shape
+    send = torch.empty(B_local * D_total, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().tbe_a2a_pooled_pack(ptr(grad), ptr(send), ptr(dims), dims.numel(), B_local, D_total,
+                                              int(vec), scale, stream_ptr(dev)), "tbe_a2a_pooled_pack")
+    return send
+
 
 
 def _unpack(recv, feat_out_col, feat_src, feat_slab_col, slab_offset, slab_stride, B_local, D_total, vec, scale):
@@ -41,3 +65,5 @@ def _pack(grad, feat_out_col, feat_src, feat_slab_col, slab_offset, slab_stride,
 
 _impl.impl("pooled_exchange_unpack", _unpack)
 _impl.impl("pooled_exchange_pack", _pack)
+_impl.impl("a2a_pooled_unpack", _simple_unpack)
+_impl.impl("a2a_pooled_pack", _simple_pack)

@@ -60,6 +60,16 @@ class DistributedModelParallel(nn.Module):
             if p.device != self.device:
                 raise RuntimeError("dense parameters must live on the DMP device")
         if self._env.world_size > 1 and dense:
+            # sharded tables (buffers of the TBE modules) differ per rank and must neither be
+            # broadcast at DDP construction nor reduced (model_parallel.py:84-100 does the same)
+            ignore = []
+            for path, sub in m.named_modules():
+                if isinstance(sub, ShardedEmbeddingBagCollection):
+                    for n, _ in nn.Module.named_buffers(sub):
+                        ignore.append(f"{path}.{n}" if path else n)
+                    for n, _ in nn.Module.named_parameters(sub):
+                        ignore.append(f"{path}.{n}" if path else n)
+            DistributedDataParallel._set_params_and_buffers_to_ignore_for_model(m, ignore)
             self._dmp_wrapped_module = DistributedDataParallel(
                 m, device_ids=[self.device.index] if self.device.type == "cuda" else None,
                 process_group=self._env.process_group, gradient_as_bucket_view=True, broadcast_buffers=False,
