@@ -285,7 +285,7 @@ int tbe_pooled_exchange_pack(const float* grad, float* send, const int32_t* feat
  *   dense [B, D], sparse [B, F, D] contiguous, out / grad_out [B, D + (F+1)F/2]:
  *   out[b] = [dense[b] | <X_i, X_j> for i < j in torch.triu_indices(F+1, F+1, 1) order],
  *   X = [dense[b]; sparse[b]].
- * forward: 1 <= F <= 31, D % 4 == 0, D <= 256.  backward: F <= 27, D in {16, 32, 64, 128}.
+ * forward: 1 <= F <= 31, D in {16, 32, 64, 128, 256}.  backward: F <= 27, D in {16, 32, 64, 128}.
  * ---------------------------------------------------------------------------------- */
 int tbe_dlrm_interaction_forward_f32(const float* dense, const float* sparse, int32_t B,
                                      int32_t F, int32_t D, float* out, void* stream);

@@ -12,7 +12,8 @@
 // A wave owns one sample at a time: X = [dense; sparse] (R = F+1 <= 32 rows) is staged in an LDS
 // tile private to the wave, products run on v_mfma_f32_16x16x4_f32 (exact f32: a k-ordered fmaf
 // chain, so the oracle reproduces it bit for bit), results are re-staged in LDS and stored
-// coalesced.  No inter-wave synchronisation.
+// coalesced.  No inter-wave synchronisation.  The next sample's global loads are issued before
+// the current sample's MFMA loop (register double buffering) so HBM latency hides behind it.
 //   forward : Z = X X^T, 3 of the 4 16x16 tiles (upper triangle), K = D
 //   backward: dX = (G + G^T) X with G the strict upper-triangular matrix of d(flat),
 //             2 x D/16 tiles, K = R; d(dense) additionally receives d(out)[:, :D].
@@ -33,35 +34,78 @@ __device__ __forceinline__ void wave_lds_fence() {
 // index of pair (i, j), i < j < R, in torch.triu_indices(R, R, offset=1) row-major order
 __device__ __forceinline__ int triu_index(int i, int j, int R) { return i * (2 * R - i - 1) / 2 + (j - i - 1); }
 
+// inverse: row i of pair p (closed form + integer correction; exact for R <= 64)
+__device__ __forceinline__ int triu_row(int p, int R) {
+  const int t = 2 * R - 1;
+  int i = static_cast<int>((static_cast<float>(t) - sqrtf(static_cast<float>(t * t - 8 * p))) * 0.5f);
+  i = max(0, min(i, R - 2));
+  while (i + 1 <= R - 2 && (i + 1) * (2 * R - (i + 1) - 1) / 2 <= p) ++i;
+  while (i > 0 && i * (2 * R - i - 1) / 2 > p) --i;
+  return i;
+}
+
+// Per-lane chunks of X: VPL float4 per lane cover R*D floats (D a power of two >= 16).
+template <int D>
+struct XLoader {
+  static constexpr int LOG_V = (D == 16 ? 2 : D == 32 ? 3 : D == 64 ? 4 : D == 128 ? 5 : 6);  // log2(D/4)
+  __device__ static __forceinline__ const float* src(const float* dense, const float* sparse, int64_t b, int F, int v) {
+    const int r = v >> LOG_V;
+    const int c = (v & ((1 << LOG_V) - 1)) * 4;
+    return r == 0 ? dense + b * D + c : sparse + (b * F + (r - 1)) * D + c;
+  }
+};
+
+template <int D>
 __global__ __launch_bounds__(256, 2) void interaction_fwd_kernel(const float* __restrict__ dense,
                                                                  const float* __restrict__ sparse,
-                                                                 float* __restrict__ out, int B, int F, int D) {
+                                                                 float* __restrict__ out, int B, int F) {
   extern __shared__ float smem[];
+  constexpr int XS = D + 2;  // row stride: (2*row + k) % 32 distinct over a half-wave => no bank conflict
+  constexpr int LOG_V = XLoader<D>::LOG_V;
+  constexpr int MAXV = (32 * D / 4 + kWave - 1) / kWave;  // float4 per lane for up to 32 rows
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int R = F + 1;
   const int P = R * (R - 1) / 2;
   const int OUT = D + P;
-  const int XS = D + 2;  // row stride: (2*row + k) % 32 distinct over a half-wave => no bank conflict
   const int per_wave = 32 * XS + ((P + 3) & ~3);
   float* xs = smem + wave * per_wave;
   float* zs = xs + 32 * XS;
   const int r16 = lane & 15;
   const int kq = lane >> 4;
-  const int nvec = R * D / 4;
+  const int nvec = R * (D / 4);
+  const int stride_b = gridDim.x * 4;
 
-  for (int b = blockIdx.x * 4 + wave; b < B; b += gridDim.x * 4) {
-    // stage X: row 0 = dense[b], rows 1..F = sparse[b]
-    for (int v = lane; v < nvec; v += kWave) {
-      const int e = v * 4;
-      const int r = e / D;
-      const int c = e - r * D;
-      const float* src = (r == 0) ? dense + static_cast<int64_t>(b) * D + c
-                                  : sparse + (static_cast<int64_t>(b) * F + (r - 1)) * D + c;
-      const float4 x = ld4(src);
-      float2* dst = reinterpret_cast<float2*>(xs + r * XS + c);
-      dst[0] = make_float2(x.x, x.y);
-      dst[1] = make_float2(x.z, x.w);
+  float4 pre[MAXV];
+  int b = blockIdx.x * 4 + wave;
+  if (b < B) {
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int v = lane + i * kWave;
+      if (v < nvec) pre[i] = ld4(XLoader<D>::src(dense, sparse, b, F, v));
+    }
+  }
+  for (; b < B; b += stride_b) {
+    // registers -> LDS tile (row 0 = dense[b], rows 1..F = sparse[b])
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int v = lane + i * kWave;
+      if (v < nvec) {
+        const int r = v >> LOG_V;
+        const int c = (v & ((1 << LOG_V) - 1)) * 4;
+        float2* dst = reinterpret_cast<float2*>(xs + r * XS + c);
+        dst[0] = make_float2(pre[i].x, pre[i].y);
+        dst[1] = make_float2(pre[i].z, pre[i].w);
+      }
+    }
+    // prefetch the next sample while this one is multiplied
+    const int nb = b + stride_b;
+    if (nb < B) {
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i) {
+        const int v = lane + i * kWave;
+        if (v < nvec) pre[i] = ld4(XLoader<D>::src(dense, sparse, nb, F, v));
+      }
     }
     wave_lds_fence();
     f32x4 acc00 = {0.f, 0.f, 0.f, 0.f}, acc01 = acc00, acc11 = acc00;
@@ -103,6 +147,8 @@ __global__ __launch_bounds__(256, 2) void interaction_bwd_kernel(const float* __
   constexpr int XS = D + 16;  // B-operand reads (16k + 16n + c) % 32: conflict-free over a half-wave
   constexpr int GS = 34;      // A-operand reads (2*row + k) % 32: conflict-free
   constexpr int XROWS = 28;   // K steps cover rows 0..27
+  constexpr int LOG_V = XLoader<D>::LOG_V;
+  constexpr int MAXV = (XROWS * D / 4 + kWave - 1) / kWave;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int R = F + 1;
@@ -112,33 +158,76 @@ __global__ __launch_bounds__(256, 2) void interaction_bwd_kernel(const float* __
   float* gs = xs + XROWS * XS;
   const int r16 = lane & 15;
   const int kq = lane >> 4;
-  const int nvec = R * D / 4;
+  const int nvec = R * (D / 4);
   const int ksteps = (R + 3) / 4;
+  const int stride_b = gridDim.x * 4;
   // rows R..27 of X and the whole of G start as zeros; per sample only defined entries are rewritten
   for (int e = lane; e < XROWS * XS; e += kWave) xs[e] = 0.f;
   for (int e = lane; e < 32 * GS; e += kWave) gs[e] = 0.f;
+  // this lane's pairs (i, j) of the strict upper triangle: p = lane + 64*t
+  constexpr int MAXP = (28 * 27 / 2 + kWave - 1) / kWave;  // 6
+  int pij[MAXP];
+#pragma unroll
+  for (int t = 0; t < MAXP; ++t) {
+    const int p = lane + t * kWave;
+    int i = 0, j = 1;
+    if (p < P) {
+      i = triu_row(p, R);
+      j = i + 1 + (p - i * (2 * R - i - 1) / 2);
+    }
+    pij[t] = (i << 8) | j;
+  }
   wave_lds_fence();
 
-  for (int b = blockIdx.x * 4 + wave; b < B; b += gridDim.x * 4) {
-    for (int v = lane; v < nvec; v += kWave) {
-      const int e = v * 4;
-      const int r = e / D;
-      const int c = e - r * D;
-      const float* src = (r == 0) ? dense + static_cast<int64_t>(b) * D + c
-                                  : sparse + (static_cast<int64_t>(b) * F + (r - 1)) * D + c;
-      st4(xs + r * XS + c, ld4(src));
+  float4 pre[MAXV];
+  float gpre[MAXP];
+  int b = blockIdx.x * 4 + wave;
+  if (b < B) {
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int v = lane + i * kWave;
+      if (v < nvec) pre[i] = ld4(XLoader<D>::src(dense, sparse, b, F, v));
+    }
+#pragma unroll
+    for (int t = 0; t < MAXP; ++t) {
+      const int p = lane + t * kWave;
+      gpre[t] = p < P ? grad_out[static_cast<int64_t>(b) * OUT + D + p] : 0.f;
+    }
+  }
+  for (; b < B; b += stride_b) {
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int v = lane + i * kWave;
+      if (v < nvec) st4(xs + (v >> LOG_V) * XS + (v & ((1 << LOG_V) - 1)) * 4, pre[i]);
+    }
+#pragma unroll
+    for (int t = 0; t < MAXP; ++t) {
+      if (lane + t * kWave < P) {
+        const int i = pij[t] >> 8, j = pij[t] & 255;
+        gs[i * GS + j] = gpre[t];
+        gs[j * GS + i] = gpre[t];
+      }
     }
     const float* grow = grad_out + static_cast<int64_t>(b) * OUT;
-    for (int p = lane; p < P; p += kWave) {
-      const float g = grow[D + p];
-      int i = 0, rem = p;
-      while (rem >= R - 1 - i) {  // row of pair p in the strict upper triangle
-        rem -= R - 1 - i;
-        ++i;
+    float4 gdense = make_float4(0.f, 0.f, 0.f, 0.f);  // d(out)[:, :D] slice this lane adds to row 0
+    if (lane < D / 4) {
+      gdense.x = grow[lane * 4 + 0];
+      gdense.y = grow[lane * 4 + 1];
+      gdense.z = grow[lane * 4 + 2];
+      gdense.w = grow[lane * 4 + 3];
+    }
+    const int nb = b + stride_b;
+    if (nb < B) {
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i) {
+        const int v = lane + i * kWave;
+        if (v < nvec) pre[i] = ld4(XLoader<D>::src(dense, sparse, nb, F, v));
       }
-      const int j = i + 1 + rem;
-      gs[i * GS + j] = g;
-      gs[j * GS + i] = g;
+#pragma unroll
+      for (int t = 0; t < MAXP; ++t) {
+        const int p = lane + t * kWave;
+        gpre[t] = p < P ? grad_out[static_cast<int64_t>(nb) * OUT + D + p] : 0.f;
+      }
     }
     wave_lds_fence();
     f32x4 acc[2][NT];
@@ -169,19 +258,22 @@ __global__ __launch_bounds__(256, 2) void interaction_bwd_kernel(const float* __
           if (row < R) xs[row * XS + 16 * n + r16] = acc[m][n][q];
         }
     wave_lds_fence();
-    for (int v = lane; v < nvec; v += kWave) {
-      const int e = v * 4;
-      const int r = e / D;
-      const int c = e - r * D;
-      float4 x = ld4(xs + r * XS + c);
-      if (r == 0) {
-        x.x += grow[c + 0];
-        x.y += grow[c + 1];
-        x.z += grow[c + 2];
-        x.w += grow[c + 3];
-        st4(grad_dense + static_cast<int64_t>(b) * D + c, x);
-      } else {
-        st4(grad_sparse + (static_cast<int64_t>(b) * F + (r - 1)) * D + c, x);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int v = lane + i * kWave;
+      if (v < nvec) {
+        const int r = v >> LOG_V;
+        const int c = (v & ((1 << LOG_V) - 1)) * 4;
+        float4 x = ld4(xs + r * XS + c);
+        if (r == 0) {  // v == lane < D/4 here
+          x.x += gdense.x;
+          x.y += gdense.y;
+          x.z += gdense.z;
+          x.w += gdense.w;
+          st4(grad_dense + static_cast<int64_t>(b) * D + c, x);
+        } else {
+          st4(grad_sparse + (static_cast<int64_t>(b) * F + (r - 1)) * D + c, x);
+        }
       }
     }
     wave_lds_fence();
@@ -198,27 +290,44 @@ static unsigned interaction_grid(int B) {
   return static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(want, 256 * 2)));
 }
 
+template <typename K>
+static bool reserve_lds(K kernel, size_t bytes) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             static_cast<int>(bytes)) == hipSuccess;
+}
+
 extern "C" int tbe_dlrm_interaction_forward_f32(const float* dense, const float* sparse, int32_t B, int32_t F,
                                                 int32_t D, float* out, void* stream) {
   TBE_REQUIRE(B >= 0 && F >= 1 && F <= 31, "tbe_dlrm_interaction_forward_f32: F=%d outside [1, 31]", F);
-  TBE_REQUIRE(D >= 4 && D <= 256 && D % 4 == 0, "tbe_dlrm_interaction_forward_f32: D=%d must be a multiple of 4 in [4, 256]", D);
+  TBE_REQUIRE(D == 16 || D == 32 || D == 64 || D == 128 || D == 256,
+              "tbe_dlrm_interaction_forward_f32: D=%d not in {16,32,64,128,256}", D);
   if (B == 0) return TBE_OK;
   TBE_REQUIRE(dense && sparse && out, "tbe_dlrm_interaction_forward_f32: null pointer");
   TBE_REQUIRE(((reinterpret_cast<uintptr_t>(dense) | reinterpret_cast<uintptr_t>(sparse)) & 15) == 0,
               "tbe_dlrm_interaction_forward_f32: inputs must be 16-B aligned");
   const int R = F + 1, P = R * (R - 1) / 2;
   const size_t lds = 4 * (static_cast<size_t>(32) * (D + 2) + ((P + 3) & ~3)) * sizeof(float);
-  static size_t fwd_lds_set = 0;
-  if (lds > fwd_lds_set) {  // dynamic LDS above 64 KB must be opted into
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(interaction_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            static_cast<int>(lds)) != hipSuccess) {
-      set_error("tbe_dlrm_interaction_forward_f32: cannot reserve %zu B of LDS", lds);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid(interaction_grid(B));
+  static bool attr_set = false;
+  if (!attr_set) {  // dynamic LDS above 64 KB must be opted into
+    const size_t big = 4 * (static_cast<size_t>(32) * (256 + 2) + 496) * sizeof(float);
+    if (!reserve_lds(interaction_fwd_kernel<128>, big) || !reserve_lds(interaction_fwd_kernel<256>, big) ||
+        !reserve_lds(interaction_fwd_kernel<64>, big)) {
+      set_error("tbe_dlrm_interaction_forward_f32: cannot reserve LDS");
       return TBE_ERR_LAUNCH;
     }
-    fwd_lds_set = lds;
+    attr_set = true;
   }
-  hipLaunchKernelGGL(interaction_fwd_kernel, dim3(interaction_grid(B)), dim3(256), lds, static_cast<hipStream_t>(stream),
-                     dense, sparse, out, B, F, D);
+#define TBE_IF(DD) hipLaunchKernelGGL(interaction_fwd_kernel<DD>, grid, dim3(256), lds, st, dense, sparse, out, B, F)
+  switch (D) {
+    case 16: TBE_IF(16); break;
+    case 32: TBE_IF(32); break;
+    case 64: TBE_IF(64); break;
+    case 128: TBE_IF(128); break;
+    default: TBE_IF(256); break;
+  }
+#undef TBE_IF
   TBE_CHECK_LAUNCH("tbe_dlrm_interaction_forward_f32");
   return TBE_OK;
 }
@@ -236,23 +345,24 @@ extern "C" int tbe_dlrm_interaction_backward_f32(const float* dense, const float
   hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t lds = 4 * (static_cast<size_t>(28) * (D + 16) + 32 * 34) * sizeof(float);
   const dim3 grid(interaction_grid(B));
-  static bool bwd_lds_set = false;
-  if (!bwd_lds_set) {
-    const int big = static_cast<int>(4 * (28 * (128 + 16) + 32 * 34) * sizeof(float));
-    bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(interaction_bwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, big) == hipSuccess;
-    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(interaction_bwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, big) == hipSuccess;
-    if (!ok) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    const size_t big = 4 * (28 * (128 + 16) + 32 * 34) * sizeof(float);
+    if (!reserve_lds(interaction_bwd_kernel<8>, big) || !reserve_lds(interaction_bwd_kernel<4>, big)) {
       set_error("tbe_dlrm_interaction_backward_f32: cannot reserve LDS");
       return TBE_ERR_LAUNCH;
     }
-    bwd_lds_set = true;
+    attr_set = true;
   }
+#define TBE_IB(NT) \
+  hipLaunchKernelGGL(interaction_bwd_kernel<NT>, grid, dim3(256), lds, st, dense, sparse, grad_out, grad_dense, grad_sparse, B, F)
   switch (D) {
-    case 16: hipLaunchKernelGGL(interaction_bwd_kernel<1>, grid, dim3(256), lds, st, dense, sparse, grad_out, grad_dense, grad_sparse, B, F); break;
-    case 32: hipLaunchKernelGGL(interaction_bwd_kernel<2>, grid, dim3(256), lds, st, dense, sparse, grad_out, grad_dense, grad_sparse, B, F); break;
-    case 64: hipLaunchKernelGGL(interaction_bwd_kernel<4>, grid, dim3(256), lds, st, dense, sparse, grad_out, grad_dense, grad_sparse, B, F); break;
-    default: hipLaunchKernelGGL(interaction_bwd_kernel<8>, grid, dim3(256), lds, st, dense, sparse, grad_out, grad_dense, grad_sparse, B, F); break;
+    case 16: TBE_IB(1); break;
+    case 32: TBE_IB(2); break;
+    case 64: TBE_IB(4); break;
+    default: TBE_IB(8); break;
   }
+#undef TBE_IB
   TBE_CHECK_LAUNCH("tbe_dlrm_interaction_backward_f32");
   return TBE_OK;
 }

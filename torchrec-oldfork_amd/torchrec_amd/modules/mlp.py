@@ -6,6 +6,46 @@ import torch
 from torch import nn
 
 
+class _LinearSplitKWgrad(torch.autograd.Function):
+    """y = x W^T + b with the weight gradient computed as a batched GEMM over batch chunks.
+
+    dW = dY^T X has a tiny output (out x in, e.g. 256 x 512) and a huge reduction dimension (the
+    batch, 65 536): a plain GEMM launches ~50 workgroups on a 256-CU chip.  Splitting the batch
+    into `chunks` slices turns it into one batched GEMM with `chunks` x more workgroups plus a
+    small sum — the split-K the BLAS heuristic does not pick for this shape.  fp32 throughout;
+    only the summation order of the batch reduction changes."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, chunks):
+        ctx.save_for_backward(x, weight)
+        ctx.chunks = chunks
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gy @ weight if ctx.needs_input_grad[0] else None
+        B = x.shape[0]
+        c = ctx.chunks
+        if c > 1 and B % c == 0:
+            gw = torch.bmm(gy.view(c, B // c, -1).transpose(1, 2), x.view(c, B // c, -1)).sum(dim=0)
+        else:
+            gw = gy.t() @ x
+        gb = gy.sum(dim=0) if ctx.has_bias else None
+        return gx, gw, gb, None
+
+
+def _wgrad_chunks(batch: int, out_f: int, in_f: int) -> int:
+    """Chunks for the split-K weight gradient: enough (128 x 128)-tile workgroups to fill 256 CUs."""
+    tiles = max(1, (out_f + 127) // 128) * max(1, (in_f + 127) // 128)
+    c = 1
+    while tiles * c < 256 and c < 32 and batch % (2 * c) == 0 and batch // (2 * c) >= 1024:
+        c *= 2
+    return c
+
+
 class Perceptron(nn.Module):
     def __init__(self, in_size: int, out_size: int, bias: bool = True,
                  activation: Union[nn.Module, Callable[[torch.Tensor], torch.Tensor]] = torch.relu,
@@ -16,7 +56,12 @@ class Perceptron(nn.Module):
         self._activation_fn = activation
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
-        return self._activation_fn(self._linear(input))
+        lin = self._linear
+        if input.is_cuda and input.dim() == 2 and torch.is_grad_enabled() and lin.weight.requires_grad:
+            c = _wgrad_chunks(input.shape[0], self._out_size, self._in_size)
+            if c > 1:
+                return self._activation_fn(_LinearSplitKWgrad.apply(input, lin.weight, lin.bias, c))
+        return self._activation_fn(lin(input))
 
 
 class MLP(nn.Module):
