@@ -298,6 +298,10 @@ int tbe_dlrm_interaction_backward_f32(const float* dense, const float* sparse,
 int tbe_jagged_2d_to_dense_f32(const float* values, const int64_t* offsets, int32_t B,
                                int32_t D, int32_t max_L, float* dense, void* stream);
 
+/* Gradient of the above: values_grad [N, D] <- dense_grad [B, max_L, D] (rows beyond max_L get 0). */
+int tbe_dense_to_jagged_2d_f32(const float* dense, const int64_t* offsets, int32_t B, int32_t D,
+                               int32_t max_L, int64_t N, float* values, void* stream);
+
 /* torch.ops.fbgemm.offsets_range (torchrec/modules/feature_processor.py:65):
  * out[i] = i - offsets[bag(i)] for i in [0, range_size). offsets has n entries (no total). */
 int tbe_offsets_range(const int64_t* offsets, int64_t n, int64_t range_size, int64_t* out,

@@ -76,36 +76,18 @@ __global__ __launch_bounds__(256, 2) void interaction_fwd_kernel(const float* __
   const int nvec = R * (D / 4);
   const int stride_b = gridDim.x * 4;
 
-  float4 pre[MAXV];
-  int b = blockIdx.x * 4 + wave;
-  if (b < B) {
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      const int v = lane + i * kWave;
-      if (v < nvec) pre[i] = ld4(XLoader<D>::src(dense, sparse, b, F, v));
-    }
-  }
-  for (; b < B; b += stride_b) {
-    // registers -> LDS tile (row 0 = dense[b], rows 1..F = sparse[b])
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      const int v = lane + i * kWave;
-      if (v < nvec) {
-        const int r = v >> LOG_V;
-        const int c = (v & ((1 << LOG_V) - 1)) * 4;
-        float2* dst = reinterpret_cast<float2*>(xs + r * XS + c);
-        dst[0] = make_float2(pre[i].x, pre[i].y);
-        dst[1] = make_float2(pre[i].z, pre[i].w);
-      }
-    }
-    // prefetch the next sample while this one is multiplied
-    const int nb = b + stride_b;
-    if (nb < B) {
-#pragma unroll
-      for (int i = 0; i < MAXV; ++i) {
-        const int v = lane + i * kWave;
-        if (v < nvec) pre[i] = ld4(XLoader<D>::src(dense, sparse, nb, F, v));
-      }
+  (void)MAXV;
+  for (int b = blockIdx.x * 4 + wave; b < B; b += stride_b) {
+    // global -> LDS tile (row 0 = dense[b], rows 1..F = sparse[b]).  A register-prefetch of the
+    // next sample was tried and lost 50 %: hipcc serialises it behind vmcnt(0); latency is hidden
+    // by the second wave on the SIMD instead.
+    for (int v = lane; v < nvec; v += kWave) {
+      const float4 x = ld4(XLoader<D>::src(dense, sparse, b, F, v));
+      const int r = v >> LOG_V;
+      const int c = (v & ((1 << LOG_V) - 1)) * 4;
+      float2* dst = reinterpret_cast<float2*>(xs + r * XS + c);
+      dst[0] = make_float2(x.x, x.y);
+      dst[1] = make_float2(x.z, x.w);
     }
     wave_lds_fence();
     f32x4 acc00 = {0.f, 0.f, 0.f, 0.f}, acc01 = acc00, acc11 = acc00;

@@ -308,6 +308,26 @@ __global__ __launch_bounds__(256) void jagged_2d_to_dense_kernel(const float* __
   }
 }
 
+// Gradient of jagged_2d_to_dense: values_grad[offsets[b] + l, :] = dense_grad[b, l, :] for l < min(len_b, max_L),
+// zero for the truncated tail (l >= max_L).
+__global__ __launch_bounds__(256) void dense_to_jagged_2d_kernel(const float* __restrict__ dense,
+                                                                const int64_t* __restrict__ offsets, int B, int D,
+                                                                int max_L, int64_t N, float* __restrict__ values) {
+  const int64_t total = N * D;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int d = static_cast<int>(i % D);
+    const int64_t row = i / D;
+    int lo = 0, hi = B;  // largest b with offsets[b] <= row
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (offsets[mid] <= row) lo = mid; else hi = mid;
+    }
+    const int64_t l = row - offsets[lo];
+    values[i] = l < max_L ? dense[(static_cast<int64_t>(lo) * max_L + l) * D + d] : 0.f;
+  }
+}
+
 __global__ __launch_bounds__(256) void offsets_range_kernel(const int64_t* __restrict__ offsets, int64_t n,
                                                            int64_t range_size, int64_t* __restrict__ out) {
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < range_size;
@@ -561,6 +581,17 @@ extern "C" int tbe_jagged_2d_to_dense_f32(const float* values, const int64_t* of
   hipLaunchKernelGGL(jagged_2d_to_dense_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), values,
                      offsets, B, D, max_L, dense);
   TBE_CHECK_LAUNCH("tbe_jagged_2d_to_dense_f32");
+  return TBE_OK;
+}
+
+extern "C" int tbe_dense_to_jagged_2d_f32(const float* dense, const int64_t* offsets, int32_t B, int32_t D,
+                                          int32_t max_L, int64_t N, float* values, void* stream) {
+  TBE_REQUIRE(B >= 0 && D >= 0 && max_L >= 0 && N >= 0, "tbe_dense_to_jagged_2d_f32: bad sizes");
+  if (N * D == 0) return TBE_OK;
+  TBE_REQUIRE(B > 0 && dense && offsets && values, "tbe_dense_to_jagged_2d_f32: null pointer");
+  hipLaunchKernelGGL(dense_to_jagged_2d_kernel, dim3(grid_for(N * D)), dim3(256), 0, static_cast<hipStream_t>(stream), dense,
+                     offsets, B, D, max_L, N, values);
+  TBE_CHECK_LAUNCH("tbe_dense_to_jagged_2d_f32");
   return TBE_OK;
 }
 

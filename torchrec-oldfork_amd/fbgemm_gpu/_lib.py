@@ -107,6 +107,8 @@ SIGNATURES = {
         ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p]),
     "tbe_jagged_2d_to_dense_f32": (
         ctypes.c_int, [c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p, c_void_p]),
+    "tbe_dense_to_jagged_2d_f32": (
+        ctypes.c_int, [c_void_p, c_void_p, c_i32, c_i32, c_i32, c_i64, c_void_p, c_void_p]),
     "tbe_offsets_range": (ctypes.c_int, [c_void_p, c_i64, c_i64, c_void_p, c_void_p]),
 }
 

@@ -194,6 +194,32 @@ def jagged_2d_to_dense_forward(values: torch.Tensor, offsets: torch.Tensor,
     return dense
 
 
+def _jagged_2d_to_dense_setup(ctx, inputs, output):
+    values, offsets, max_sequence_length = inputs
+    ctx.save_for_backward(offsets)
+    ctx.max_L = max_sequence_length
+    ctx.N, ctx.D = values.shape
+
+
+def _jagged_2d_to_dense_backward(ctx, grad_dense):
+    (offsets,) = ctx.saved_tensors
+    if not grad_dense.is_cuda:
+        raise RuntimeError("jagged_2d_to_dense backward: no CPU fallback in the MI355X build")
+    dev = grad_dense.device
+    g = grad_dense.contiguous().float()
+    offs = offsets.to(torch.int64).contiguous().view(-1)
+    B = offs.numel() - 1
+    grad_values = torch.empty((ctx.N, ctx.D), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().tbe_dense_to_jagged_2d_f32(ptr(g), ptr(offs), B, ctx.D, ctx.max_L, ctx.N,
+                                                     ptr(grad_values), stream_ptr(dev)),
+              "tbe_dense_to_jagged_2d_f32")
+    return grad_values, None, None
+
+
+torch.library.register_autograd("fbgemm::jagged_2d_to_dense", _jagged_2d_to_dense_backward,
+                                setup_context=_jagged_2d_to_dense_setup)
+
 _impl_lib.impl("asynchronous_complete_cumsum", asynchronous_complete_cumsum)
 _impl_lib.impl("asynchronous_inclusive_cumsum", asynchronous_inclusive_cumsum)
 _impl_lib.impl("asynchronous_exclusive_cumsum", asynchronous_exclusive_cumsum)
