@@ -11,7 +11,7 @@
 //  1. linearize : key[p] = feat_row_base[f] + indices[p]  (invalid index -> sentinel),
 //                 payload[p] = (bag << 32) | p             (thread per bag, coalesced at L = 1)
 //  2. sort      : stable LSD radix sort of (key, payload) on the low key_bits bits
-//                 (rocPRIM device radix sort)
+//                 (hand-written, radix_sort.hpp: 8-bit digits, ballot-based stable ranking)
 //  3. update    : the sorted contributions are cut into fixed chunks of C; one G-lane group
 //                 walks a chunk, 4 gradient rows + 4 weight rows in flight, accumulates
 //                 runs of equal keys in registers and applies the optimizer when a run
@@ -24,11 +24,10 @@
 #include <cstdlib>
 #include <cstring>
 
-#include <rocprim/device/device_radix_sort.hpp>
-
 #include <algorithm>
 
 #include "common.hpp"
+#include "radix_sort.hpp"
 
 namespace tbe {
 
@@ -624,17 +623,9 @@ struct BwdWorkspace {
   float* partial_last;
   int32_t* origin_list;
   int32_t* origin_count;
-  void* sort_tmp;
-  size_t sort_tmp_bytes;
+  RadixWorkspace sort;
   size_t total;
 };
-
-template <typename KeyT>
-static hipError_t sort_pairs(void* tmp, size_t& tmp_bytes, KeyT* kin, KeyT* kout, uint64_t* vin,
-                             uint64_t* vout, int64_t N, int key_bits, hipStream_t st) {
-  return rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, static_cast<size_t>(N), 0u,
-                                   static_cast<unsigned>(key_bits), st, false);
-}
 
 static int carve(void* ws, int64_t N, int32_t max_D, int32_t key_bits, BwdWorkspace* out) {
   const bool k64 = key_bits > 32;
@@ -642,13 +633,7 @@ static int carve(void* ws, int64_t N, int32_t max_D, int32_t key_bits, BwdWorksp
   const int C = pick_chunk(N);
   const int64_t nchunks = (N + C - 1) / C;
   const int max_D_pad = (max_D + 3) / 4 * 4;
-  size_t sort_bytes = 0;
-  hipError_t e = k64 ? sort_pairs<uint64_t>(nullptr, sort_bytes, nullptr, nullptr, nullptr, nullptr, N, key_bits, nullptr)
-                     : sort_pairs<uint32_t>(nullptr, sort_bytes, nullptr, nullptr, nullptr, nullptr, N, key_bits, nullptr);
-  if (e != hipSuccess) {
-    set_error("rocprim radix_sort_pairs size query failed: %s", hipGetErrorString(e));
-    return TBE_ERR_LAUNCH;
-  }
+  const size_t sort_bytes = radix_carve(nullptr, N, key_bits).bytes;
   Carver c(ws);
   out->keys_in = c.take_bytes(N * ksz);
   out->keys_out = c.take_bytes(N * ksz);
@@ -658,8 +643,7 @@ static int carve(void* ws, int64_t N, int32_t max_D, int32_t key_bits, BwdWorksp
   out->partial_last = c.take<float>(nchunks * max_D_pad);
   out->origin_list = c.take<int32_t>(nchunks);
   out->origin_count = c.take<int32_t>(1);
-  out->sort_tmp = c.take_bytes(sort_bytes);
-  out->sort_tmp_bytes = sort_bytes;
+  out->sort = radix_carve(c.take_bytes(sort_bytes), N, key_bits);
   out->total = c.total();
   return TBE_OK;
 }
@@ -711,8 +695,10 @@ static int run_backward(BwdArgs a, const BwdWorkspace& w, int32_t max_D, hipStre
   ProfileSpan total_span(phase == kPhasePrepare ? -1 : TBE_PROFILE_BWD_TOTAL, st);
   KeyT* kin = static_cast<KeyT*>(w.keys_in);
   KeyT* kout = static_cast<KeyT*>(w.keys_out);
-  a.keys_sorted = kout;
-  a.payload_sorted = w.pay_out;
+  // the sort ping-pongs between the two buffer pairs: an odd number of passes ends in the second
+  const bool in_second = (radix_passes(a.key_bits) & 1) != 0;
+  a.keys_sorted = in_second ? static_cast<void*>(kout) : static_cast<void*>(kin);
+  a.payload_sorted = in_second ? w.pay_out : w.pay_in;
   if (phase & kPhasePrepare) {
   ProfileSpan prep_span(TBE_PROFILE_BWD_PREPARE, st);
   if (a.pooling_mode == TBE_POOL_NONE) {
@@ -733,12 +719,8 @@ static int run_backward(BwdArgs a, const BwdWorkspace& w, int32_t max_D, hipStre
     set_error("tbe_backward: hipMemsetAsync failed");
     return TBE_ERR_LAUNCH;
   }
-  size_t tmp_bytes = w.sort_tmp_bytes;
-  hipError_t e = sort_pairs<KeyT>(w.sort_tmp, tmp_bytes, kin, kout, w.pay_in, w.pay_out, a.N, a.key_bits, st);
-  if (e != hipSuccess) {
-    set_error("tbe_backward: radix sort failed: %s", hipGetErrorString(e));
-    return TBE_ERR_LAUNCH;
-  }
+  const int where = radix_sort_pairs<KeyT>(kin, kout, w.pay_in, w.pay_out, a.N, a.key_bits, w.sort, st);
+  if (where < 0) return where;
   }  // prepare
   if (!(phase & kPhaseApply)) return TBE_OK;
   if (max_D <= 64) return launch_update<KeyT, 16, 1>(a, st);
