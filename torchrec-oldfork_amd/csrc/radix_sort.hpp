@@ -3,8 +3,9 @@
 //
 // 8-bit digits, ceil(key_bits / 8) passes, 3 launches per pass, no inter-workgroup
 // synchronisation inside a launch (nothing to dead-lock, nothing stale):
-//   1. radix_hist_kernel   : per-tile 256-bin histogram (LDS atomics) -> hist[digit][tile], and the
-//                            pass's global digit totals (integer global atomics: order-independent).
+//   0. radix_totals_kernel : once per sort: digit totals of EVERY pass (they do not depend on the order
+//                            of the keys), per-workgroup partial counts, no global atomics.
+//   1. radix_hist_kernel   : per-tile 256-bin histogram (LDS atomics) -> hist[digit][tile].
 //   2. radix_offsets_kernel: one workgroup per digit: digit base = sum of lower digits' totals, then
 //                            an exclusive scan of that digit's row over the tiles (in place).
 //   3. radix_scatter_kernel: a tile = 4 waves x 16 rounds x 64 keys in input order.  Rank inside a
@@ -19,13 +20,16 @@
 namespace tbe {
 
 constexpr int kSortThreads = 256;
-constexpr int kSortRounds = 16;                                  // rounds of 64 keys per wave
+constexpr int kSortRounds = 8;                                   // rounds of 64 keys per wave
 constexpr int kSortTile = kSortThreads * kSortRounds;            // 4096 keys per workgroup
 constexpr int kSortWaves = kSortThreads / kWave;
+constexpr int kTotalsBlocks = 256;
+constexpr int kMaxPasses = 8;
 
 struct RadixWorkspace {
   uint32_t* hist;    // [256][ntiles]
-  uint32_t* totals;  // [passes][256]
+  uint32_t* totals_part;  // [kTotalsBlocks][passes][256] per-workgroup partial digit totals
+  uint32_t* totals;       // [passes][256]
   size_t bytes;
 };
 
@@ -36,15 +40,15 @@ inline RadixWorkspace radix_carve(void* base, int64_t N, int key_bits) {
   Carver c(base);
   RadixWorkspace w;
   w.hist = c.take<uint32_t>(256 * static_cast<size_t>(radix_tiles(N)));
-  w.totals = c.take<uint32_t>(256 * static_cast<size_t>(radix_passes(key_bits)));
+  w.totals_part = c.take<uint32_t>(static_cast<size_t>(kTotalsBlocks) * 256 * radix_passes(key_bits));
+  w.totals = c.take<uint32_t>(static_cast<size_t>(256) * radix_passes(key_bits));
   w.bytes = c.total();
   return w;
 }
 
 template <typename KeyT>
 __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(const KeyT* __restrict__ keys, int64_t N, int shift,
-                                                                 uint32_t* __restrict__ hist, uint32_t* __restrict__ totals,
-                                                                 int64_t ntiles) {
+                                                                 uint32_t* __restrict__ hist, int64_t ntiles) {
   __shared__ uint32_t h[256];
   h[threadIdx.x] = 0;
   __syncthreads();
@@ -55,9 +59,37 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(const KeyT* __
     if (i < N) atomicAdd(&h[(keys[i] >> shift) & 255], 1u);
   }
   __syncthreads();
-  const uint32_t c = h[threadIdx.x];
-  hist[static_cast<int64_t>(threadIdx.x) * ntiles + blockIdx.x] = c;
-  if (c) atomicAdd(&totals[threadIdx.x], c);
+  hist[static_cast<int64_t>(threadIdx.x) * ntiles + blockIdx.x] = h[threadIdx.x];
+}
+
+// Digit totals of all passes, once per sort (independent of key order).  grid = kTotalsBlocks.
+template <typename KeyT>
+__global__ __launch_bounds__(kSortThreads) void radix_totals_kernel(const KeyT* __restrict__ keys, int64_t N, int passes,
+                                                                   uint32_t* __restrict__ totals_part) {
+  __shared__ uint32_t h[kMaxPasses * 256];
+  for (int i = threadIdx.x; i < passes * 256; i += kSortThreads) h[i] = 0;
+  __syncthreads();
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kSortThreads + threadIdx.x; i < N;
+       i += static_cast<int64_t>(gridDim.x) * kSortThreads) {
+    const KeyT k = keys[i];
+    for (int p = 0; p < passes; ++p) atomicAdd(&h[p * 256 + static_cast<int>((k >> (8 * p)) & 255)], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < passes * 256; i += kSortThreads)
+    totals_part[static_cast<int64_t>(blockIdx.x) * passes * 256 + i] = h[i];
+}
+
+// grid = passes * 256 workgroups: workgroup (p, d) sums the kTotalsBlocks partial counts of digit d.
+__global__ __launch_bounds__(kSortThreads) void radix_totals_reduce_kernel(const uint32_t* __restrict__ totals_part,
+                                                                          int passes, uint32_t* __restrict__ totals) {
+  __shared__ uint32_t wave_tot[kSortWaves];
+  const int pd = blockIdx.x;  // p * 256 + d
+  uint32_t s = threadIdx.x < kTotalsBlocks ? totals_part[static_cast<int64_t>(threadIdx.x) * passes * 256 + pd] : 0u;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, kWave);
+  if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) totals[pd] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
 }
 
 // grid = 256 workgroups (one per digit)
@@ -69,7 +101,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_offsets_kernel(uint32_t* _
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   // digit base = sum of totals of lower digits
-  uint32_t s = threadIdx.x < d ? totals[threadIdx.x] : 0u;
+  uint32_t s = static_cast<int>(threadIdx.x) < d ? totals[threadIdx.x] : 0u;
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, kWave);
   if (lane == 0) wave_tot[wave] = s;
@@ -181,20 +213,21 @@ inline int radix_sort_pairs(KeyT* k0, KeyT* k1, uint64_t* v0, uint64_t* v1, int6
   }
   const int passes = radix_passes(key_bits);
   const int64_t ntiles = radix_tiles(N);
-  if (hipMemsetAsync(ws.totals, 0, sizeof(uint32_t) * 256 * passes, st) != hipSuccess) {
-    set_error("radix_sort_pairs: memset failed");
-    return TBE_ERR_LAUNCH;
+  if (passes > kMaxPasses) {
+    set_error("radix_sort_pairs: key_bits too large");
+    return TBE_ERR_UNSUPPORTED;
   }
+  hipLaunchKernelGGL((radix_totals_kernel<KeyT>), dim3(kTotalsBlocks), dim3(kSortThreads), 0, st, k0, N, passes, ws.totals_part);
+  hipLaunchKernelGGL(radix_totals_reduce_kernel, dim3(passes * 256), dim3(kSortThreads), 0, st, ws.totals_part, passes, ws.totals);
   int cur = 0;
   for (int p = 0; p < passes; ++p) {
     const KeyT* kin = cur ? k1 : k0;
     const uint64_t* vin = cur ? v1 : v0;
     KeyT* kout = cur ? k0 : k1;
     uint64_t* vout = cur ? v0 : v1;
-    uint32_t* totals = ws.totals + 256 * p;
     hipLaunchKernelGGL((radix_hist_kernel<KeyT>), dim3(static_cast<unsigned>(ntiles)), dim3(kSortThreads), 0, st, kin, N,
-                       8 * p, ws.hist, totals, ntiles);
-    hipLaunchKernelGGL(radix_offsets_kernel, dim3(256), dim3(kSortThreads), 0, st, ws.hist, totals, ntiles);
+                       8 * p, ws.hist, ntiles);
+    hipLaunchKernelGGL(radix_offsets_kernel, dim3(256), dim3(kSortThreads), 0, st, ws.hist, ws.totals + 256 * p, ntiles);
     hipLaunchKernelGGL((radix_scatter_kernel<KeyT>), dim3(static_cast<unsigned>(ntiles)), dim3(kSortThreads), 0, st, kin,
                        vin, kout, vout, N, 8 * p, ws.hist, ntiles);
     cur ^= 1;
