@@ -16,16 +16,26 @@ class _LinearSplitKWgrad(torch.autograd.Function):
     only the summation order of the batch reduction changes."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, chunks):
-        ctx.save_for_backward(x, weight)
+    def forward(ctx, x, weight, bias, chunks, fuse_relu):
         ctx.chunks = chunks
         ctx.has_bias = bias is not None
+        ctx.fuse_relu = fuse_relu
+        if fuse_relu:
+            # bias + ReLU in the GEMM epilogue (hipBLASLt): no separate activation kernel
+            out = torch._addmm_activation(bias, x, weight.t(), use_gelu=False)
+            ctx.save_for_backward(x, weight, out)
+            return out
+        ctx.save_for_backward(x, weight)
         return torch.nn.functional.linear(x, weight, bias)
 
     @staticmethod
     def backward(ctx, gy):
-        x, weight = ctx.saved_tensors
-        gy = gy.contiguous()
+        if ctx.fuse_relu:
+            x, weight, out = ctx.saved_tensors
+            gy = torch.ops.aten.threshold_backward(gy.contiguous(), out, 0.0)
+        else:
+            x, weight = ctx.saved_tensors
+            gy = gy.contiguous()
         gx = gy @ weight if ctx.needs_input_grad[0] else None
         B = x.shape[0]
         c = ctx.chunks
@@ -34,7 +44,7 @@ class _LinearSplitKWgrad(torch.autograd.Function):
         else:
             gw = gy.t() @ x
         gb = gy.sum(dim=0) if ctx.has_bias else None
-        return gx, gw, gb, None
+        return gx, gw, gb, None, None
 
 
 def _wgrad_chunks(batch: int, out_f: int, in_f: int) -> int:
@@ -59,8 +69,10 @@ class Perceptron(nn.Module):
         lin = self._linear
         if input.is_cuda and input.dim() == 2 and torch.is_grad_enabled() and lin.weight.requires_grad:
             c = _wgrad_chunks(input.shape[0], self._out_size, self._in_size)
-            if c > 1:
-                return self._activation_fn(_LinearSplitKWgrad.apply(input, lin.weight, lin.bias, c))
+            relu = self._activation_fn is torch.relu and lin.bias is not None
+            if c > 1 or relu:
+                y = _LinearSplitKWgrad.apply(input, lin.weight, lin.bias, c, relu)
+                return y if relu else self._activation_fn(y)
         return self._activation_fn(lin(input))
 
 
