@@ -18,13 +18,15 @@ class _Fn(torch.autograd.Function):
         ctx.save_for_backward(indices, offsets, psw)
         out, _ = oracle.tbe_forward(mod.tables, indices.numpy(), offsets.numpy(),
                                     psw.numpy() if psw is not None else None, mod.pooling)
+        if mod.pooling == oracle.POOL_NONE:
+            return torch.from_numpy(out)
         return mod._to_layout(torch.from_numpy(out))
 
     @staticmethod
     def backward(ctx, grad):
         indices, offsets, psw = ctx.saved_tensors
         mod = ctx.mod
-        g = mod._from_layout(grad.contiguous())
+        g = grad.contiguous() if mod.pooling == oracle.POOL_NONE else mod._from_layout(grad.contiguous())
         oracle.tbe_backward(mod.tables, indices.numpy(), offsets.numpy(), g.numpy(), oracle.OPT_EXACT_SGD,
                             mod.optimizer_args.learning_rate, psw.numpy() if psw is not None else None, mod.pooling)
         return None, None, None, None, None
@@ -71,3 +73,7 @@ class OracleTBE(nn.Module):
 
 def oracle_tbe_factory(specs, ftm, pooling_mode, device, fused_params):
     return OracleTBE(specs, ftm, pooling_mode, device, fused_params)
+
+
+def oracle_seq_tbe_factory(specs, ftm, device, fused_params):
+    return OracleTBE(specs, ftm, oracle.POOL_NONE, device, fused_params)

@@ -225,3 +225,81 @@ def test_dlrm_e2e_dmp_ddp_pipeline_world2():
         for n, (w, _) in s.items():
             seen[n] += w.shape[0]
     assert seen == rows
+
+
+def _seq_worker(rank, W, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=W)
+    try:
+        import _cpu_ops
+        _cpu_ops.register()
+        from _oracle_tbe import oracle_seq_tbe_factory
+        from torchrec_amd.distributed.embedding import ShardedEmbeddingCollection
+        from torchrec_amd.distributed.types import ParameterSharding, ShardingEnv
+        from torchrec_amd.modules.embedding_configs import EmbeddingConfig
+        from torchrec_amd.sparse.jagged_tensor import KeyedJaggedTensor
+
+        rows, D, B = [30, 11, 19], 4, 5
+        keys = ["a", "b", "c"]
+        cfgs = [EmbeddingConfig(name=f"t{i}", embedding_dim=D, num_embeddings=rows[i], feature_names=[keys[i]]) for i in range(3)]
+        plan = {"t0": ParameterSharding("table_wise", "batched_fused", [1]),
+                "t1": ParameterSharding("table_wise", "batched_fused", [0]),
+                "t2": ParameterSharding("table_wise", "batched_fused", [1])}
+        sec = ShardedEmbeddingCollection(cfgs, plan, ShardingEnv.from_process_group(dist.group.WORLD),
+                                         {"learning_rate": 0.5}, torch.device("cpu"), oracle_seq_tbe_factory)
+        init = [np.random.default_rng(100 + t).standard_normal((rows[t], D)).astype(np.float32) for t in range(3)]
+        for name, w in sec.local_shards().items():
+            w.copy_(torch.from_numpy(init[int(name[1:])]))
+        rng = np.random.default_rng(7 + rank)
+        lengths = rng.integers(0, 4, size=3 * B).astype(np.int32)
+        vals = np.concatenate([rng.integers(0, rows[f], size=int(lengths[f * B:(f + 1) * B].sum())) for f in range(3)]).astype(np.int64)
+        kjt = KeyedJaggedTensor.from_lengths_sync(keys, torch.from_numpy(vals), torch.from_numpy(lengths))
+        out = sec(kjt).wait()
+        embs = {k: out[k].values() for k in keys}
+        cat = torch.cat([embs[k] for k in keys])
+        g = np.random.default_rng(70 + rank).standard_normal(tuple(cat.shape)).astype(np.float32)
+        cat.backward(torch.from_numpy(g))
+        ret[rank] = ({k: embs[k].detach().numpy().copy() for k in keys}, lengths, vals, g,
+                     {n: w.clone().numpy() for n, w in sec.local_shards().items()})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_sequence_embedding_world2():
+    from oracle import oracle
+
+    W = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_seq_worker, args=(W, _free_port(), ret), nprocs=W, join=True)
+    rows, D, B = [30, 11, 19], 4, 5
+    init = [np.random.default_rng(100 + t).standard_normal((rows[t], D)).astype(np.float32) for t in range(3)]
+    keys = ["a", "b", "c"]
+    tabs = oracle.Tables(rows, [D] * 3)
+    for t in range(3):
+        tabs.weights[t][...] = init[t]
+    # forward: each rank's per-feature rows are plain gathers
+    for r in range(W):
+        embs, lengths, vals, g, _ = ret[r]
+        pos = np.concatenate([[0], np.cumsum([lengths[f * B:(f + 1) * B].sum() for f in range(3)])])
+        for f, k in enumerate(keys):
+            np.testing.assert_array_equal(embs[k], init[f][vals[pos[f]:pos[f + 1]]])
+    # backward: global batch = concat over ranks per feature, grads / W, exact SGD
+    g_vals, g_grad, g_len = [], [], []
+    for f in range(3):
+        for r in range(W):
+            embs, lengths, vals, g, _ = ret[r]
+            pos = np.concatenate([[0], np.cumsum([lengths[ff * B:(ff + 1) * B].sum() for ff in range(3)])])
+            g_vals.append(vals[pos[f]:pos[f + 1]])
+            g_grad.append(g[pos[f]:pos[f + 1]] / W)
+            g_len.append(lengths[f * B:(f + 1) * B])
+    g_vals, g_grad, g_len = np.concatenate(g_vals), np.concatenate(g_grad), np.concatenate(g_len)
+    offs = np.concatenate([[0], np.cumsum(g_len)]).astype(np.int64)
+    oracle.tbe_backward(tabs, g_vals, offs, g_grad, oracle.OPT_EXACT_SGD, 0.5, None, oracle.POOL_NONE)
+    seen = set()
+    for r in range(W):
+        for name, w in ret[r][4].items():
+            np.testing.assert_allclose(w, tabs.weights[int(name[1:])], rtol=1e-5, atol=1e-5)
+            seen.add(name)
+    assert seen == {"t0", "t1", "t2"}

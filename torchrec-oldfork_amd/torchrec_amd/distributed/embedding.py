@@ -1,0 +1,141 @@
+"""ShardedEmbeddingCollection: table-wise sharded UNPOOLED ("sequence") embeddings
+(torchrec/distributed/embedding.py:293-539, sharding/tw_sequence_sharding.py,
+SequenceEmbeddingAllToAll dist_data.py:841-932, All2All_Seq_Req comm_ops.py:608-749).
+
+Data path per step (W ranks, rank r owns the features of its tables):
+  ids    : 2-phase exchange (lengths, then values; sizes are data dependent for sequences) — ids
+           arrive as [src rank][local feature][sample], which is the order the local TBE
+           (PoolingMode.NONE) consumes and produces, so no recat permute is needed;
+  lookup : one tbe_forward_nobag_f32 launch -> [N_recv, D];
+  output : ONE all-to-all of embedding rows; because the received ids of source w are contiguous, the
+           send buffer is the lookup output as is, and what comes back is in the order of the ids this
+           rank sent — i.e. already grouped [feature][sample] per destination, from which the
+           per-feature JaggedTensors are sliced without a copy when features are sent in
+           collection order;
+  grads  : the same all-to-all reversed (x 1/W, comm_ops.py:704-706), then the fused TBE backward.
+Row-wise sequence sharding (bucketize + unbucketize_permute) is not implemented.
+"""
+from typing import Any, Callable, Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from ..modules.embedding_configs import EmbeddingConfig
+from ..sparse.jagged_tensor import JaggedTensor, KeyedJaggedTensor
+from . import embeddingbag as _eb
+from .types import Awaitable, LazyAwaitable, NoWait, ParameterSharding, ShardingEnv, ShardingType
+
+
+def _default_seq_tbe_factory(specs, ftm, device, fused_params):
+    from fbgemm_gpu.split_table_batched_embeddings_ops import (
+        ComputeDevice, EmbeddingLocation, PoolingMode, SplitTableBatchedEmbeddingBagsCodegen)
+
+    return SplitTableBatchedEmbeddingBagsCodegen(
+        embedding_specs=[(r, d, EmbeddingLocation.DEVICE, ComputeDevice.CUDA) for r, d in specs],
+        feature_table_map=ftm, pooling_mode=PoolingMode.NONE, device=device, **fused_params)
+
+
+class _SeqExchange(torch.autograd.Function):
+    """rows [sum(send_counts), D] -> rows [sum(recv_counts), D]; backward is the reverse exchange / W."""
+
+    @staticmethod
+    def forward(ctx, emb, pg, send_counts, recv_counts):
+        ctx.pg, ctx.send_counts, ctx.recv_counts = pg, send_counts, recv_counts
+        D = emb.shape[1]
+        out = torch.empty((sum(recv_counts), D), dtype=emb.dtype, device=emb.device)
+        dist.all_to_all_single(out, emb.contiguous(), list(recv_counts), list(send_counts), group=pg)  # splits in rows
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        D = grad.shape[1]
+        W = dist.get_world_size(ctx.pg)
+        g = grad.contiguous()
+        if _eb.GRADIENT_DIVISION:
+            g = g / W
+        out = torch.empty((sum(ctx.send_counts), D), dtype=g.dtype, device=g.device)
+        dist.all_to_all_single(out, g, list(ctx.send_counts), list(ctx.recv_counts), group=ctx.pg)
+        return out, None, None, None
+
+
+class ShardedEmbeddingCollection(nn.Module):
+    def __init__(self, tables: List[EmbeddingConfig], table_name_to_parameter_sharding: Dict[str, ParameterSharding],
+                 env: ShardingEnv, fused_params: Optional[Dict[str, Any]] = None, device: Optional[torch.device] = None,
+                 tbe_factory: Optional[Callable] = None) -> None:
+        super().__init__()
+        self._pg, self._W, self._me = env.process_group, env.world_size, env.rank
+        self._device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        dims = {c.embedding_dim for c in tables}
+        if len(dims) != 1:
+            raise ValueError("All tables in a EmbeddingCollection are required to have same embedding dimension.")
+        self.embedding_dim = dims.pop()
+        self._configs = list(tables)
+        self._feature_names: List[str] = []
+        g_table: List[int] = []
+        for t, c in enumerate(tables):
+            for f in (c.feature_names or [c.name]):
+                self._feature_names.append(f)
+                g_table.append(t)
+        owner = []
+        for c in tables:
+            ps = table_name_to_parameter_sharding[c.name]
+            if ps.sharding_type != ShardingType.TABLE_WISE.value:
+                raise NotImplementedError("sequence embeddings: only table_wise sharding is implemented")
+            owner.append(int(ps.ranks[0]))
+        Fg = len(self._feature_names)
+        self._local_feats = [[g for g in range(Fg) if owner[g_table[g]] == r] for r in range(self._W)]
+        self._send_order = [g for lf in self._local_feats for g in lf]
+        self._send_per_rank = [len(lf) for lf in self._local_feats]
+        self._F_local = len(self._local_feats[self._me])
+        local_tables: List[int] = []
+        for g in self._local_feats[self._me]:
+            if g_table[g] not in local_tables:
+                local_tables.append(g_table[g])
+        self._local_table_ids = local_tables
+        ftm_local = [local_tables.index(g_table[g]) for g in self._local_feats[self._me]]
+        self._emb_module = None
+        if local_tables:
+            factory = tbe_factory or _default_seq_tbe_factory
+            self._emb_module = factory([(tables[t].num_embeddings, tables[t].embedding_dim) for t in local_tables],
+                                       ftm_local * self._W, self._device, dict(fused_params or {}))
+            for t, w in zip(local_tables, self._emb_module.split_embedding_weights()):
+                w.uniform_(tables[t].get_weight_init_min(), tables[t].get_weight_init_max())
+
+    def local_shards(self) -> Dict[str, torch.Tensor]:
+        if self._emb_module is None:
+            return {}
+        return {self._configs[t].name: w for t, w in zip(self._local_table_ids, self._emb_module.split_embedding_weights())}
+
+    def forward(self, features: KeyedJaggedTensor) -> Awaitable[Dict[str, JaggedTensor]]:
+        W, B, pg = self._W, features.stride(), self._pg
+        pos = {k: i for i, k in enumerate(features.keys())}
+        order = [pos[self._feature_names[g]] for g in self._send_order]
+        sent = features if order == list(range(len(features.keys()))) else features.permute(order)
+        lengths, values = sent.lengths(), sent.values()
+        lpk = sent.length_per_key()
+        val_in, k = [], 0
+        for n in self._send_per_rank:
+            val_in.append(sum(lpk[k:k + n]))
+            k += n
+        if W > 1:
+            recv_l = torch.empty(W * self._F_local * B, dtype=lengths.dtype, device=lengths.device)
+            dist.all_to_all_single(recv_l, lengths, [self._F_local * B] * W, [n * B for n in self._send_per_rank], group=pg)
+            val_out = recv_l.view(W, -1).sum(dim=1).cpu().tolist() if self._F_local else [0] * W
+            recv_v = torch.empty(sum(val_out), dtype=values.dtype, device=values.device)
+            dist.all_to_all_single(recv_v, values, val_out, val_in, group=pg)
+        else:
+            recv_l, recv_v, val_out = lengths, values, val_in
+        D = self.embedding_dim
+        if self._emb_module is not None and self._F_local:
+            offsets = torch.ops.fbgemm.asynchronous_complete_cumsum(recv_l).long()
+            emb = self._emb_module(recv_v, offsets)
+        else:
+            emb = torch.zeros((0, D), dtype=torch.float32, device=self._device)
+        back = _SeqExchange.apply(emb, pg, val_out, val_in) if W > 1 else emb
+        # `back` is ordered like `sent` (dest rank, its local features, samples)
+        opk = sent.offset_per_key()
+        out: Dict[str, JaggedTensor] = {}
+        for i, g in enumerate(self._send_order):
+            out[self._feature_names[g]] = JaggedTensor(values=back[opk[i]:opk[i + 1]], lengths=lengths[i * B:(i + 1) * B])
+        return NoWait({k: out[k] for k in self._feature_names})
