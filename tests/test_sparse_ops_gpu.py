@@ -133,3 +133,36 @@ def test_offsets_range_and_jagged_2d_to_dense():
     for max_l in (1, 5, 12):
         d = torch.ops.fbgemm.jagged_2d_to_dense(cu(values), cu(offsets), max_l)
         np.testing.assert_array_equal(d.cpu().numpy(), oracle.jagged_2d_to_dense(values, offsets, max_l))
+
+
+def test_full_size_index_op_properties():
+    """BASELINE-size (26 features x batch 65 536) properties that need no oracle run:
+    cumsum: last element == sum, differences == input; permute: applying a permutation and its
+    inverse is the identity, lengths/values travel together; bucketize: unbucketize_permute inverts the
+    placement and per-bucket ids fall inside the block."""
+    F, B, W = 26, 65536, 8
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0)
+    lengths = torch.randint(0, 4, (F * B,), generator=g, device="cuda", dtype=torch.int32)
+    offs = torch.ops.fbgemm.asynchronous_complete_cumsum(lengths)
+    assert int(offs[-1]) == int(lengths.sum()) and int(offs[0]) == 0
+    assert torch.equal(offs[1:] - offs[:-1], lengths)
+    N = int(offs[-1])
+    values = torch.randint(0, 1 << 40, (N,), generator=g, device="cuda", dtype=torch.int64)
+    perm = torch.randperm(F, generator=g, device="cuda").to(torch.int32)
+    inv = torch.empty_like(perm)
+    inv[perm.long()] = torch.arange(F, device="cuda", dtype=torch.int32)
+    l1, v1, _ = torch.ops.fbgemm.permute_2D_sparse_data(perm, lengths.view(F, B), values, None, N)
+    assert torch.equal(l1, lengths.view(F, B)[perm.long()])
+    l2, v2, _ = torch.ops.fbgemm.permute_2D_sparse_data(inv, l1, v1, None, N)
+    assert torch.equal(l2.view(-1), lengths) and torch.equal(v2, values)
+    rows = torch.randint(W, 1 << 26, (F,), generator=g, device="cuda", dtype=torch.int64)
+    blocks = (rows + W - 1) // W
+    feat_of = torch.repeat_interleave(torch.arange(F, device="cuda").repeat_interleave(B), lengths.long())
+    ids = (torch.rand(N, generator=g, device="cuda", dtype=torch.float64) * rows[feat_of]).long()
+    nl, ni, _, _, unb = torch.ops.fbgemm.block_bucketize_sparse_features(lengths, ids, False, True, blocks, W, None)
+    assert int(nl.sum()) == N
+    assert torch.equal(ni[unb], ids % blocks[feat_of])          # inverse placement
+    noffs = torch.ops.fbgemm.asynchronous_complete_cumsum(nl)
+    bucket_of_dst = torch.bucketize(torch.arange(N, device="cuda"), noffs[:: F * B][1:].contiguous(), right=True)
+    assert torch.equal(bucket_of_dst[unb], ids // blocks[feat_of])  # each id landed in its bucket's segment

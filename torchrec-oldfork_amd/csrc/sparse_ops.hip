@@ -245,6 +245,61 @@ __global__ __launch_bounds__(256) void bucketize_scatter_kernel(
   }
 }
 
+// Same two steps with the per-bag bucket counters in LDS (my_size <= 32): layout [bucket][thread]
+// puts a thread's counters in one bank column, so the increments never conflict.
+constexpr int kBucketizeLdsMaxBuckets = 32;
+
+template <typename LenT, typename IdxT>
+__global__ __launch_bounds__(256) void bucketize_count_lds_kernel(const int64_t* __restrict__ offsets,
+                                                                 int64_t lengths_size, int B,
+                                                                 const IdxT* __restrict__ indices,
+                                                                 const IdxT* __restrict__ block_sizes, int my_size,
+                                                                 LenT* __restrict__ new_lengths) {
+  extern __shared__ int32_t cnt[];  // [my_size][256]
+  for (int p = 0; p < my_size; ++p) cnt[p * 256 + threadIdx.x] = 0;
+  const int64_t bag = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (bag >= lengths_size) return;
+  const int f = static_cast<int>(bag / B);
+  const uint64_t blk = static_cast<uint64_t>(block_sizes[f]);
+  const int64_t s = offsets[bag], e = offsets[bag + 1];
+  for (int64_t i = s; i < e; ++i) {
+    const uint64_t p = static_cast<uint64_t>(indices[i]) / blk;
+    if (p < static_cast<uint64_t>(my_size)) cnt[p * 256 + threadIdx.x] += 1;
+  }
+  for (int p = 0; p < my_size; ++p)
+    new_lengths[static_cast<int64_t>(p) * lengths_size + bag] = static_cast<LenT>(cnt[p * 256 + threadIdx.x]);
+}
+
+template <typename LenT, typename IdxT>
+__global__ __launch_bounds__(256) void bucketize_scatter_lds_kernel(
+    const int64_t* __restrict__ offsets, int64_t lengths_size, int B, const IdxT* __restrict__ indices,
+    const IdxT* __restrict__ block_sizes, int my_size, const float* __restrict__ weights,
+    const int64_t* __restrict__ new_offsets, IdxT* __restrict__ new_indices, float* __restrict__ new_weights,
+    IdxT* __restrict__ new_pos, IdxT* __restrict__ unbucketize_permute) {
+  extern __shared__ int32_t cur[];  // [my_size][256] running position inside (bucket, bag)
+  for (int p = 0; p < my_size; ++p) cur[p * 256 + threadIdx.x] = 0;
+  const int64_t bag = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (bag >= lengths_size) return;
+  const int f = static_cast<int>(bag / B);
+  const uint64_t blk = static_cast<uint64_t>(block_sizes[f]);
+  const int64_t s = offsets[bag], e = offsets[bag + 1];
+  for (int64_t i = s; i < e; ++i) {
+    const uint64_t idx = static_cast<uint64_t>(indices[i]);
+    const uint64_t p = idx / blk;
+    if (p >= static_cast<uint64_t>(my_size)) {
+      if (unbucketize_permute != nullptr) unbucketize_permute[i] = static_cast<IdxT>(-1);
+      continue;
+    }
+    const int c = cur[p * 256 + threadIdx.x];
+    cur[p * 256 + threadIdx.x] = c + 1;
+    const int64_t dst = new_offsets[static_cast<int64_t>(p) * lengths_size + bag] + c;
+    new_indices[dst] = static_cast<IdxT>(idx - p * blk);
+    if (weights != nullptr) new_weights[dst] = weights[i];
+    if (new_pos != nullptr) new_pos[dst] = static_cast<IdxT>(i - s);
+    if (unbucketize_permute != nullptr) unbucketize_permute[i] = static_cast<IdxT>(dst);
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // Pooled all-to-all layout copies: [src][B_local][D_src] slabs <-> [B_local, sum D_src].
 // One thread per 16-B (VEC=4) or 4-B (VEC=1) element of the [B_local, D_total] matrix.
@@ -478,9 +533,27 @@ int run_bucketize(const void* lengths, int64_t lengths_size, const void* indices
   const int64_t nl = lengths_size * my_size;
   int rc = run_scan<LenT, int64_t>(static_cast<const LenT*>(lengths), w.offsets, lengths_size, nullptr, 1, 0, w.scan_ws, nullptr, st);
   if (rc != TBE_OK) return rc;
+  const unsigned grid = static_cast<unsigned>((lengths_size + 255) / 256);
+  if (my_size <= kBucketizeLdsMaxBuckets) {
+    // per-thread bucket counters / cursors live in LDS ([bucket][thread], conflict-free): no global
+    // read-modify-write, no memsets, new_lengths written coalesced
+    const size_t lds = static_cast<size_t>(my_size) * 256 * sizeof(int32_t);
+    hipLaunchKernelGGL((bucketize_count_lds_kernel<LenT, IdxT>), dim3(grid), dim3(256), lds, st, w.offsets, lengths_size, B,
+                       static_cast<const IdxT*>(indices), static_cast<const IdxT*>(block_sizes), my_size,
+                       static_cast<LenT*>(new_lengths));
+    TBE_CHECK_LAUNCH("bucketize count");
+    rc = run_scan<LenT, int64_t>(static_cast<const LenT*>(new_lengths), w.new_offsets, nl, nullptr, 1, 0, w.scan_ws, nullptr, st);
+    if (rc != TBE_OK) return rc;
+    hipLaunchKernelGGL((bucketize_scatter_lds_kernel<LenT, IdxT>), dim3(grid), dim3(256), lds, st, w.offsets, lengths_size, B,
+                       static_cast<const IdxT*>(indices), static_cast<const IdxT*>(block_sizes), my_size, weights,
+                       w.new_offsets, static_cast<IdxT*>(new_indices), new_weights,
+                       bucketize_pos ? static_cast<IdxT*>(new_pos) : nullptr,
+                       sequence ? static_cast<IdxT*>(unbucketize_permute) : nullptr);
+    TBE_CHECK_LAUNCH("bucketize scatter");
+    return TBE_OK;
+  }
   (void)hipMemsetAsync(new_lengths, 0, nl * sizeof(LenT), st);
   (void)hipMemsetAsync(w.cursor, 0, nl * sizeof(int32_t), st);
-  const unsigned grid = static_cast<unsigned>((lengths_size + 255) / 256);
   hipLaunchKernelGGL((bucketize_count_kernel<LenT, IdxT>), dim3(grid), dim3(256), 0, st, w.offsets, lengths_size, B,
                      static_cast<const IdxT*>(indices), static_cast<const IdxT*>(block_sizes), my_size,
                      static_cast<LenT*>(new_lengths));
