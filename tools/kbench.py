@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--opt", default="EXACT_SGD")
     ap.add_argument("--nbatches", type=int, default=8)
+    ap.add_argument("--pooling", type=int, default=1, help="ids per bag (fixed pooling factor)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     rows = [min(r, args.cap) if args.cap else r for r in CRITEO_ROWS]
@@ -42,9 +43,10 @@ def main():
     g.manual_seed(1234)
     batches = []
     for _ in range(args.nbatches):
-        idx = torch.cat([torch.randint(0, r, (B,), generator=g, device=dev, dtype=torch.int64) for r in rows])
+        idx = torch.cat([torch.randint(0, r, (B * args.pooling,), generator=g, device=dev, dtype=torch.int64) for r in rows])
         batches.append(idx)
-    offsets = torch.arange(F * B + 1, dtype=torch.int64, device=dev)
+    L = args.pooling
+    offsets = torch.arange(F * B + 1, dtype=torch.int64, device=dev) * L
     grad = torch.randn(B, F * D, device=dev)
 
     def timeit(fn, n):
@@ -66,7 +68,7 @@ def main():
             outs["o"] = mod(batches[i % len(batches)], offsets)
 
     ms_f = timeit(fwd, args.iters)
-    fwd_bytes = B * (F * D * 4 + F * 8 + F * 8 + F * D * 4)
+    fwd_bytes = B * (F * L * (D * 4 + 8) + F * 8 + F * D * 4)
     print(f"fwd: {ms_f * 1e3:.1f} us  {fwd_bytes / ms_f / 1e6:.1f} GB/s (algorithmic {fwd_bytes / 1e6:.1f} MB)", flush=True)
 
     def fwdbwd(i):

@@ -17,6 +17,7 @@
 // and walks them with cross-lane broadcasts, 4 rows in flight, partial sums of the wave's
 // groups combined through LDS.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.hpp"
 
@@ -428,7 +429,11 @@ extern "C" int tbe_forward_pooled_f32(const uint64_t* feat_weights, const int32_
   const bool weighted = per_sample_weights != nullptr;
   const bool mean = pooling_mode == TBE_POOL_MEAN;
   const double avg_len = static_cast<double>(N) / (static_cast<double>(F) * B);
-  const bool long_bags = avg_len >= 12.0;
+  static const double long_min = [] {
+    const char* e = getenv("TBE_FWD_LONG_MIN");  // tuning knob
+    return e ? atof(e) : 3.5;  // measured on MI355X: the wave-per-bag kernel wins from ~4 ids per bag
+  }();
+  const bool long_bags = avg_len >= long_min;
   if (max_D <= 64) return launch_fwd<16, 1>(a, weighted, mean, long_bags, st);
   if (max_D <= 128) return launch_fwd<32, 1>(a, weighted, mean, long_bags, st);
   if (max_D <= 256) return launch_fwd<64, 1>(a, weighted, mean, long_bags, st);
