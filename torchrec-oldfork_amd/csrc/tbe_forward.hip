@@ -36,6 +36,7 @@ struct FwdArgs {
   int64_t out_stride;
   int32_t F;
   int32_t B;
+  int32_t bags_per_wave;  // 64, or 16 for small launches (more waves => more rows in flight)
 };
 
 __device__ __forceinline__ void fma4(float4& a, float w, const float4& x) {
@@ -79,7 +80,8 @@ __global__ __launch_bounds__(256) void tbe_fwd_short_kernel(FwdArgs a) {
   const int wave = threadIdx.x >> 6;
   const int f = blockIdx.x % a.F;
   const int tile = blockIdx.x / a.F;
-  const int bag0 = tile * kFwdBagsPerBlock + wave * kWave;
+  const int bpw = a.bags_per_wave;
+  const int bag0 = (tile * 4 + wave) * bpw;
   if (bag0 >= a.B) return;  // wave-uniform
 
   const float* __restrict__ W = reinterpret_cast<const float*>(a.feat_weights[f]);
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256) void tbe_fwd_short_kernel(FwdArgs a) {
   const int64_t* __restrict__ offs = a.offsets + static_cast<int64_t>(f) * a.B;
   const int b_l = bag0 + lane;
   int64_t s_l = 0, e_l = 0;
-  if (b_l < a.B) {
+  if (b_l < a.B && lane < bpw) {
     s_l = offs[b_l];
     e_l = offs[b_l + 1];
   }
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(256) void tbe_fwd_short_kernel(FwdArgs a) {
   int nbad = 0;
 
 #pragma unroll 1
-  for (int p = 0; p < kWave; p += NG * U) {
+  for (int p = 0; p < bpw; p += NG * U) {
     if (bag0 + p >= a.B) break;  // wave-uniform tail
     int64_t s[U];
     int len[U];
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(256) void tbe_fwd_short_kernel(FwdArgs a) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int b = bag0 + p + u * NG + g;
-      if (b < a.B) {
+      if (b < a.B && p + u * NG + g < bpw) {
         float scale = 1.f;
         if (MEAN) scale = len[u] > 0 ? 1.f / static_cast<float>(len[u]) : 0.f;
         float* orow = a.out + static_cast<int64_t>(b) * a.out_stride + Doff;
@@ -389,7 +391,7 @@ static int launch_fwd(const FwdArgs& a, bool weighted, bool mean, bool long_bags
     else TBE_L(false, false);
 #undef TBE_L
   } else {
-    const unsigned tiles = (a.B + kFwdBagsPerBlock - 1) / kFwdBagsPerBlock;
+    const unsigned tiles = (a.B + 4 * a.bags_per_wave - 1) / (4 * a.bags_per_wave);
     const unsigned grid = tiles * a.F;
 #define TBE_S(WG, MN) hipLaunchKernelGGL((tbe_fwd_short_kernel<G, NV, WG, MN>), dim3(grid), dim3(256), 0, st, a)
     if (weighted && mean) TBE_S(true, true);
@@ -425,7 +427,9 @@ extern "C" int tbe_forward_pooled_f32(const uint64_t* feat_weights, const int32_
   TBE_REQUIRE(N == 0 || indices != nullptr, "tbe_forward_pooled_f32: null indices");
   hipStream_t st = static_cast<hipStream_t>(stream);
   FwdArgs a{feat_weights, feat_D, feat_out_offset, feat_rows, indices, offsets, per_sample_weights,
-            out, bounds_errors, out_row_stride, F, B};
+            out, bounds_errors, out_row_stride, F, B, 64};
+  // small launches: 4x more waves (16 bags each) keep more row reads in flight per CU
+  if (static_cast<int64_t>(F) * B < (static_cast<int64_t>(1) << 19)) a.bags_per_wave = 16;
   const bool weighted = per_sample_weights != nullptr;
   const bool mean = pooling_mode == TBE_POOL_MEAN;
   const double avg_len = static_cast<double>(N) / (static_cast<double>(F) * B);
