@@ -263,8 +263,10 @@ int tbe_a2a_pooled_pack(const float* grad, float* send, const int32_t* dim_sum_p
  *   matrix:          [B_local, D_total], global feature g occupies columns
  *                    [feat_out_col[g], feat_out_col[g+1])
  *   feat_src[g] >= 0 : table-wise, lives in slab feat_src[g] at column feat_slab_col[g]
- *   feat_src[g] <  0 : row-wise, every slab holds a partial pool at column feat_slab_col[g];
+ *   feat_src[g] == -1: row-wise, every slab holds a partial pool at column feat_slab_col[g];
  *                      unpack sums them in rank order 0..W-1, pack broadcasts the gradient.
+ *   feat_src[g] <= -2: replicated (data-parallel) feature: its columns are skipped by both
+ *                      kernels (a local lookup writes / reads them, see embeddingbag.py).
  * all_multiple_of_4 != 0 asserts every column offset / dim / stride is a multiple of 4.
  * ---------------------------------------------------------------------------------- */
 int tbe_pooled_exchange_unpack(const float* recv, float* out, const int32_t* feat_out_col,

@@ -28,7 +28,8 @@ def build() -> str:
 def lib() -> ctypes.CDLL:
     global _lib
     if _lib is None:
-        if not os.path.exists(_SO):
+        srcs = [os.path.join(_HERE, f) for f in ("tbe_oracle.c", "dlrm_oracle.c")]
+        if not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
             build()
         _lib = ctypes.CDLL(_SO)
         _lib.oracle_tbe_forward_pooled.restype = ctypes.c_int64

@@ -357,6 +357,7 @@ void oracle_pooled_exchange_unpack(const float* recv, float* out, const int32_t*
       for (int32_t c = feat_out_col[g]; c < feat_out_col[g + 1]; ++c) {
         const int32_t within = feat_slab_col[g] + (c - feat_out_col[g]);
         float v;
+        if (feat_src[g] < -1) continue; /* replicated feature: columns left untouched */
         if (feat_src[g] >= 0) {
           const int32_t r = feat_src[g];
           v = recv[slab_offset[r] + (int64_t)b * slab_stride[r] + within];
@@ -376,6 +377,7 @@ void oracle_pooled_exchange_pack(const float* grad, float* send, const int32_t* 
       for (int32_t c = feat_out_col[g]; c < feat_out_col[g + 1]; ++c) {
         const int32_t within = feat_slab_col[g] + (c - feat_out_col[g]);
         const float v = grad[(int64_t)b * D_total + c] * scale;
+        if (feat_src[g] < -1) continue;
         if (feat_src[g] >= 0) {
           const int32_t r = feat_src[g];
           send[slab_offset[r] + (int64_t)b * slab_stride[r] + within] = v;

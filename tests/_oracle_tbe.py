@@ -77,3 +77,103 @@ def oracle_tbe_factory(specs, ftm, pooling_mode, device, fused_params):
 
 def oracle_seq_tbe_factory(specs, ftm, device, fused_params):
     return OracleTBE(specs, ftm, oracle.POOL_NONE, device, fused_params)
+
+
+def _scatter_cols(out, block, offs, dims, stride):
+    """out[b*stride + offs[f] + d] = block[b, Doff_f + d] on a [B, stride] view."""
+    o = out.view(-1, stride)
+    c = 0
+    for off, d in zip(offs, dims):
+        o[:, off:off + d] = block[:, c:c + d]
+        c += d
+
+
+def _gather_cols(grad, offs, dims, stride):
+    g = grad.contiguous().view(-1, stride)
+    return torch.cat([g[:, off:off + d] for off, d in zip(offs, dims)], dim=1).contiguous()
+
+
+class _FnInto(torch.autograd.Function):
+    """fused stand-in writing into a caller buffer (SplitTable...forward_into)."""
+
+    @staticmethod
+    def forward(ctx, out, placeholder, mod, indices, offsets, psw, offs, stride):
+        ctx.mod, ctx.offs, ctx.stride = mod, offs, stride
+        ctx.save_for_backward(indices, offsets, psw)
+        block, _ = oracle.tbe_forward(mod.tables, indices.numpy(), offsets.numpy(),
+                                      psw.numpy() if psw is not None else None, mod.pooling)
+        _scatter_cols(out, torch.from_numpy(block), offs, mod.tables.feat_D.tolist(), stride)
+        ctx.mark_dirty(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        indices, offsets, psw = ctx.saved_tensors
+        mod = ctx.mod
+        g = _gather_cols(grad, ctx.offs, mod.tables.feat_D.tolist(), ctx.stride)
+        oracle.tbe_backward(mod.tables, indices.numpy(), offsets.numpy(), g.numpy(), oracle.OPT_EXACT_SGD,
+                            mod.optimizer_args.learning_rate, psw.numpy() if psw is not None else None, mod.pooling)
+        return (grad,) + (None,) * 7
+
+
+def _fused_forward_into(self, out, out_offsets, row_stride, indices, offsets, psw=None):
+    return _FnInto.apply(out, self.placeholder, self, indices.long(), offsets.long(), psw, out_offsets.tolist(),
+                         int(row_stride))
+
+
+OracleTBE.forward_into = _fused_forward_into
+
+
+class _DenseFnInto(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, out, weights, mod, indices, offsets, psw, offs, stride):
+        ctx.mod, ctx.offs, ctx.stride = mod, offs, stride
+        ctx.save_for_backward(indices, offsets, psw)
+        mod._sync_tables()
+        block, _ = oracle.tbe_forward(mod.tables, indices.numpy(), offsets.numpy(),
+                                      psw.numpy() if psw is not None else None, mod.pooling)
+        _scatter_cols(out, torch.from_numpy(block), offs, mod.tables.feat_D.tolist(), stride)
+        ctx.mark_dirty(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        indices, offsets, psw = ctx.saved_tensors
+        mod = ctx.mod
+        g = _gather_cols(grad, ctx.offs, mod.tables.feat_D.tolist(), ctx.stride)
+        gw = [np.zeros((r, d), dtype=np.float32) for r, d in zip(mod.tables.rows, mod.tables.dims)]
+        oracle.tbe_backward(mod.tables, indices.numpy(), offsets.numpy(), g.numpy(), oracle.OPT_DENSE_GRAD, 0.0,
+                            psw.numpy() if psw is not None else None, mod.pooling, state0=gw)
+        flat = torch.from_numpy(np.concatenate([x.reshape(-1) for x in gw])) if gw else torch.zeros(0)
+        return (grad, flat) + (None,) * 6
+
+
+class OracleDenseTBE(nn.Module):
+    """TEST-ONLY stand-in for DenseTableBatchedEmbeddingBagsCodegen (replicated / data-parallel tables):
+    `.weights` is a real nn.Parameter so DDP all-reduces its gradient and a dense optimizer steps it."""
+
+    def __init__(self, specs, ftm, pooling_mode, device):
+        super().__init__()
+        rows, dims = [s[0] for s in specs], [s[1] for s in specs]
+        self.tables = oracle.Tables(rows, dims, ftm)
+        self.pooling = int(pooling_mode)
+        self.weights = nn.Parameter(torch.zeros(sum(r * d for r, d in zip(rows, dims))))
+
+    def split_embedding_weights(self):
+        out, o = [], 0
+        for r, d in zip(self.tables.rows, self.tables.dims):
+            out.append(self.weights.detach()[o:o + r * d].view(r, d))
+            o += r * d
+        return out
+
+    def _sync_tables(self):
+        for t, w in enumerate(self.split_embedding_weights()):
+            self.tables.weights[t][...] = w.numpy()
+
+    def forward_into(self, out, out_offsets, row_stride, indices, offsets, psw=None):
+        return _DenseFnInto.apply(out, self.weights, self, indices.long(), offsets.long(), psw, out_offsets.tolist(),
+                                  int(row_stride))
+
+
+def oracle_dp_tbe_factory(specs, ftm, pooling_mode, device):
+    return OracleDenseTBE(specs, ftm, pooling_mode, device)

@@ -44,14 +44,14 @@ def _global_data(W, B_local, fixed_len, weighted, seed=3):
     return per_rank, init
 
 
-def _worker(rank, W, port, fixed_len, weighted, n_rw, ret):
+def _worker(rank, W, port, fixed_len, weighted, n_rw, ret, dp_max_rows=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=W)
     try:
         import _cpu_ops
         _cpu_ops.register()
-        from _oracle_tbe import oracle_tbe_factory
+        from _oracle_tbe import oracle_dp_tbe_factory, oracle_tbe_factory
         from torchrec_amd.distributed.embeddingbag import ShardedEmbeddingBagCollection
         from torchrec_amd.distributed.planner import EmbeddingShardingPlanner, Topology
         from torchrec_amd.distributed.types import ShardingEnv
@@ -65,14 +65,17 @@ def _worker(rank, W, port, fixed_len, weighted, n_rw, ret):
         tables = [EmbeddingBagConfig(name=f"t{i}", embedding_dim=DIMS[i], num_embeddings=ROWS[i], feature_names=[keys[i]])
                   for i in range(len(ROWS))]
         ebc = EmbeddingBagCollection(tables, is_weighted=weighted, device=torch.device("meta"))
-        plan = EmbeddingShardingPlanner(Topology(W, "cpu"), num_row_wise=n_rw).plan_tables(tables)
+        plan = EmbeddingShardingPlanner(Topology(W, "cpu"), num_row_wise=n_rw, dp_max_rows=dp_max_rows).plan_tables(tables)
         env = ShardingEnv.from_process_group(dist.group.WORLD)
         sebc = ShardedEmbeddingBagCollection(ebc, plan, env, {"learning_rate": LR}, torch.device("cpu"),
-                                             tbe_factory=oracle_tbe_factory)
-        # load the global initial weights into the local shards
+                                             tbe_factory=oracle_tbe_factory, dp_tbe_factory=oracle_dp_tbe_factory)
+        # load the global initial weights into the local shards / replicas
         for name, (w, row0) in sebc.local_shards().items():
             t = int(name[1:])
             w.copy_(torch.from_numpy(init[t][row0:row0 + w.shape[0]]))
+        with torch.no_grad():
+            for name, w in sebc.dp_tables().items():
+                w.copy_(torch.from_numpy(init[int(name[1:])]))
         lengths, vals, wts, grad = per_rank[rank]
         if fixed_len:
             kjt = KeyedJaggedTensor.from_fixed_lengths(keys, torch.from_numpy(vals), [fixed_len] * len(keys),
@@ -85,19 +88,30 @@ def _worker(rank, W, port, fixed_len, weighted, n_rw, ret):
         vals_out = out.values()
         vals_out.backward(torch.from_numpy(grad))
         shards = {n: (w.clone().numpy(), r0) for n, (w, r0) in sebc.local_shards().items()}
+        # replicated tables: what DDP + a dense SGD would do = all-reduce(mean) of the dense grad, then step
+        if sebc._dp_module is not None:
+            g = sebc._dp_module.weights.grad.clone()
+            dist.all_reduce(g)
+            g /= W
+            with torch.no_grad():
+                sebc._dp_module.weights -= LR * g
+            for n, w in sebc.dp_tables().items():
+                shards[n] = (w.clone().numpy(), 0)
         ret[rank] = (vals_out.detach().numpy().copy(), shards, {n: p.sharding_type for n, p in plan.items()})
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("fixed_len,weighted,n_rw", [(1, False, 1), (2, True, 2), (0, False, 1), (0, True, 0), (1, False, 5)])
-def test_sharded_equals_unsharded_world2(fixed_len, weighted, n_rw):
+@pytest.mark.parametrize("fixed_len,weighted,n_rw,dp_max_rows", [
+    (1, False, 1, 0), (2, True, 2, 0), (0, False, 1, 0), (0, True, 0, 0), (1, False, 5, 0),
+    (1, False, 0, 10), (0, True, 1, 25), (2, False, 0, 100)])
+def test_sharded_equals_unsharded_world2(fixed_len, weighted, n_rw, dp_max_rows):
     from oracle import oracle
 
     W = 2
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(W, _free_port(), fixed_len, weighted, n_rw, ret), nprocs=W, join=True)
+    mp.spawn(_worker, args=(W, _free_port(), fixed_len, weighted, n_rw, ret, dp_max_rows), nprocs=W, join=True)
     per_rank, init = _global_data(W, 6, fixed_len, weighted)
     # unsharded oracle on each rank's batch (forward), then ONE backward over the global batch with
     # grads / W (GRADIENT_DIVISION, comm_ops.py:527-528)
@@ -112,6 +126,8 @@ def test_sharded_equals_unsharded_world2(fixed_len, weighted, n_rw):
         np.testing.assert_allclose(ret[r][0], ref, rtol=1e-5, atol=1e-5)
     kinds = ret[0][2]
     assert sum(1 for k in kinds.values() if k == "row_wise") == n_rw
+    n_dp = sum(1 for r in ROWS if r <= dp_max_rows)
+    assert sum(1 for k in kinds.values() if k == "data_parallel") == n_dp
     # global batch = rank-major concatenation per feature
     B = 6
     g_len = np.concatenate([np.concatenate([per_rank[r][0][f * B:(f + 1) * B] for r in range(W)]) for f in range(F)])
@@ -128,10 +144,14 @@ def test_sharded_equals_unsharded_world2(fixed_len, weighted, n_rw):
             t = int(name[1:])
             np.testing.assert_allclose(w, tabs.weights[t][row0:row0 + w.shape[0]], rtol=1e-5, atol=1e-5)
             seen_rows[t] += w.shape[0]
-    assert all(seen_rows[t] == ROWS[t] for t in range(F)), "every table row must live on exactly one rank"
+    for t in range(F):
+        replicas = W if kinds[f"t{t}"] == "data_parallel" else 1
+        assert seen_rows[t] == ROWS[t] * replicas, "sharded rows live on exactly one rank, replicated tables on all"
 
 
-def test_planner_balances_criteo_over_8_ranks():
+def test_planner_criteo_plans():
+    """26 Criteo tables: the 11 tables with <= 2500 rows are replicated (data-parallel), the other 15 are
+    placed table-wise with the smallest possible maximum per rank; nothing is row-wise (all fit)."""
     from torchrec_amd.datasets.random import CRITEO_1TB_ROWS
     from torchrec_amd.distributed.planner import EmbeddingShardingPlanner, Topology, rw_shard_rows
     from torchrec_amd.modules.embedding_configs import EmbeddingBagConfig
@@ -140,19 +160,23 @@ def test_planner_balances_criteo_over_8_ranks():
               for i, r in enumerate(CRITEO_1TB_ROWS)]
     for W in (1, 2, 4, 8):
         plan = EmbeddingShardingPlanner(Topology(W)).plan_tables(tables)
-        rw = [n for n, p in plan.items() if p.sharding_type == "row_wise"]
-        assert len(rw) == (26 % W if W > 1 else 0)
+        kinds = [p.sharding_type for p in plan.values()]
+        if W == 1:
+            assert kinds.count("table_wise") == 26
+            continue
+        assert kinds.count("data_parallel") == 11 and kinds.count("row_wise") == 0
         per_rank = [sum(1 for p in plan.values() if p.sharding_type == "table_wise" and p.ranks == [r]) for r in range(W)]
-        assert max(per_rank) - min(per_rank) == 0, per_rank  # identical lookup volume on every rank
+        assert sum(per_rank) == 15 and max(per_rank) == -(-15 // W), per_rank
         mem = [0] * W
         for t in tables:
             p = plan[t.name]
-            if p.sharding_type == "row_wise":
-                for r, n in enumerate(rw_shard_rows(t.num_embeddings, W)):
-                    mem[r] += n * 512
-            else:
+            if p.sharding_type == "table_wise":
                 mem[p.ranks[0]] += t.num_embeddings * 512
         assert max(mem) < 288e9 * 0.85
+    # capacity forces row-wise: one table larger than a GPU
+    big = [EmbeddingBagConfig(name="huge", embedding_dim=128, num_embeddings=700_000_000, feature_names=["h"])]
+    plan = EmbeddingShardingPlanner(Topology(8)).plan_tables(big)
+    assert plan["huge"].sharding_type == "row_wise"
     # rw_shard_rows examples of planner/enumerators.py:277-312
     assert rw_shard_rows(10, 3) == [4, 4, 2] and rw_shard_rows(5, 4) == [2, 2, 1, 0]
 
@@ -166,10 +190,11 @@ def _e2e_worker(rank, W, port, ret):
     try:
         import _cpu_ops
         _cpu_ops.register()
-        from _oracle_tbe import oracle_tbe_factory
+        from _oracle_tbe import oracle_dp_tbe_factory, oracle_tbe_factory
         from torchrec_amd.datasets.random import RandomRecDataset
         from torchrec_amd.distributed.embeddingbag import EmbeddingBagCollectionSharder
         from torchrec_amd.distributed.model_parallel import DistributedModelParallel
+        from torchrec_amd.distributed.planner import EmbeddingShardingPlanner, Topology
         from torchrec_amd.distributed.train_pipeline import TrainPipelineSparseDist
         from torchrec_amd.distributed.types import ShardingEnv
         from torchrec_amd.models.dlrm import DLRMTrain
@@ -189,7 +214,9 @@ def _e2e_worker(rank, W, port, ret):
                                 dense_device=dev)
         env = ShardingEnv.from_process_group(dist.group.WORLD)
         model = DistributedModelParallel(train_model, env=env, device=dev,
-                                         sharders=[EmbeddingBagCollectionSharder({"learning_rate": 0.05}, oracle_tbe_factory)])
+                                         sharders=[EmbeddingBagCollectionSharder({"learning_rate": 0.05}, oracle_tbe_factory,
+                                                                                 oracle_dp_tbe_factory)],
+                                         planner=EmbeddingShardingPlanner(Topology(W, "cpu"), dp_max_rows=10))
         opt = CombinedOptimizer([model.fused_optimizer,
                                  KeyedOptimizerWrapper(dict(model.named_parameters()), lambda p: torch.optim.SGD(p, lr=0.05))])
         data = RandomRecDataset(keys, 4, rows, manual_seed=100 + rank, num_generated_batches=3, num_batches=5, device=dev)
@@ -202,6 +229,7 @@ def _e2e_worker(rank, W, port, ret):
             losses.append(float(loss))
         dense_sd = {k: v.detach().clone() for k, v in model.named_parameters()}
         shards = {n: (w.clone().numpy(), r0) for n, (w, r0) in model.sharded_modules()[0].local_shards().items()}
+        assert set(model.sharded_modules()[0].dp_tables()) == {"t1", "t4"}  # 9 and 8 rows: replicated
         ret[rank] = (losses, {k: v.numpy() for k, v in dense_sd.items()}, shards)
     finally:
         dist.destroy_process_group()
@@ -219,7 +247,8 @@ def test_dlrm_e2e_dmp_ddp_pipeline_world2():
     for k in d0:
         np.testing.assert_allclose(d0[k], d1[k], rtol=0, atol=0)
     # every table row lives on exactly one rank
-    rows = {"t0": 50, "t1": 9, "t2": 31, "t3": 17, "t4": 8}
+    assert any("_dp_module.weights" in k for k in d0), "replicated tables must be dense parameters under DDP"
+    rows = {"t0": 50, "t2": 31, "t3": 17}  # the sharded ones
     seen = {k: 0 for k in rows}
     for s in (s0, s1):
         for n, (w, _) in s.items():

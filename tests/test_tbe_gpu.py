@@ -338,3 +338,59 @@ def test_managed_location_host_mapped_tables_match_device_tables():
         np.testing.assert_allclose(w.cpu().numpy(), tabs.weights[t], rtol=2e-5, atol=2e-5)
     for t, st in enumerate(mod.split_optimizer_states()):
         np.testing.assert_allclose(st[0].cpu().numpy(), s0[t], rtol=2e-5, atol=2e-5)
+
+
+def test_sharded_ebc_world1_with_replicated_tables_writes_one_buffer():
+    """Data-parallel (replicated) tiny tables + fused table-wise tables on one GPU: both TBE modules
+    write their column blocks of ONE [B, sum D] matrix (forward_into) and read their gradient columns from
+    it; compare with the oracle (fused exact SGD for the sharded tables, dense gradient for the replicas)."""
+    from torchrec_amd.distributed.embeddingbag import ShardedEmbeddingBagCollection
+    from torchrec_amd.distributed.planner import EmbeddingShardingPlanner, Topology
+    from torchrec_amd.distributed.types import ShardingEnv
+    from torchrec_amd.modules.embedding_configs import EmbeddingBagConfig
+    from torchrec_amd.modules.embedding_modules import EmbeddingBagCollection
+    from torchrec_amd.sparse.jagged_tensor import KeyedJaggedTensor
+
+    rng = np.random.default_rng(33)
+    rows, D, B, lr = [5000, 3, 700, 12, 90000], 128, 300, 0.1
+    keys = [f"c{i}" for i in range(len(rows))]
+    tables = [EmbeddingBagConfig(name=f"t{i}", embedding_dim=D, num_embeddings=rows[i], feature_names=[keys[i]])
+              for i in range(len(rows))]
+    ebc = EmbeddingBagCollection(tables, device=torch.device("meta"))
+    planner = EmbeddingShardingPlanner(Topology(1), constraints={"t1": ["data_parallel"], "t3": ["data_parallel"]})
+    plan = planner.plan_tables(tables)
+    assert plan["t1"].sharding_type == "data_parallel" and plan["t0"].sharding_type == "table_wise"
+    dev = torch.device("cuda", 0)
+    sebc = ShardedEmbeddingBagCollection(ebc, plan, ShardingEnv.from_local(1, 0), {"learning_rate": lr}, dev)
+    tabs = oracle.Tables(rows, [D] * len(rows))
+    init = [rng.standard_normal((r, D)).astype(np.float32) for r in rows]
+    for t in range(len(rows)):
+        tabs.weights[t][...] = init[t]
+    for name, (w, _) in sebc.local_shards().items():
+        w.copy_(torch.from_numpy(init[int(name[1:])]))
+    with torch.no_grad():
+        for name, w in sebc.dp_tables().items():
+            w.copy_(torch.from_numpy(init[int(name[1:])]))
+    values = np.concatenate([rng.integers(0, r, size=B) for r in rows]).astype(np.int64)
+    kjt = KeyedJaggedTensor.from_fixed_lengths(keys, torch.from_numpy(values).to(dev), [1] * len(keys))
+    out = sebc(kjt).wait().values()
+    offsets = np.arange(len(rows) * B + 1, dtype=np.int64)
+    ref, _ = oracle.tbe_forward(tabs, values, offsets)
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), ref)
+    grad = rng.standard_normal(tuple(out.shape)).astype(np.float32)
+    out.backward(torch.from_numpy(grad).to(dev))
+    torch.cuda.synchronize()
+    gw = [np.zeros((r, D), dtype=np.float32) for r in rows]
+    ref_tabs = oracle.Tables(rows, [D] * len(rows))
+    for t in range(len(rows)):
+        ref_tabs.weights[t][...] = init[t]
+    oracle.tbe_backward(ref_tabs, values, offsets, grad, oracle.OPT_DENSE_GRAD, 0.0, state0=gw)
+    oracle.tbe_backward(tabs, values, offsets, grad, oracle.OPT_EXACT_SGD, lr)
+    for name, (w, _) in sebc.local_shards().items():   # fused tables: updated in place
+        np.testing.assert_allclose(w.cpu().numpy(), tabs.weights[int(name[1:])], rtol=2e-5, atol=2e-5)
+    dpm = sebc._dp_module
+    flat = dpm.weights.grad.cpu().numpy()
+    for i, t in enumerate(sebc._dp_table_ids):          # replicas: untouched weights, dense gradient
+        o = dpm.weights_offsets[i]
+        np.testing.assert_allclose(flat[o:o + rows[t] * D].reshape(rows[t], D), gw[t], rtol=2e-5, atol=1e-4)
+        np.testing.assert_array_equal(dpm.split_embedding_weights()[i].cpu().numpy(), init[t])

@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256) void pooled_exchange_kernel(const float* __res
       if (s_col[mid] <= d) lo = mid; else hi = mid;
     }
     const int src = s_src[lo];
+    if (src < -1) continue;  // data-parallel (replicated) feature: not part of the exchange
     const int within = s_scol[lo] + (d - s_col[lo]);
     const int64_t mat = static_cast<int64_t>(b) * a.D_total + d;
     if (PACK) {

@@ -309,7 +309,7 @@ class _TBEBase(nn.Module):
             self._a2a_cache[B] = hit
         return hit
 
-    def _forward_impl(self, indices, offsets, per_sample_weights, B: int) -> torch.Tensor:
+    def _forward_impl(self, indices, offsets, per_sample_weights, B: int, into=None) -> torch.Tensor:
         lay = self._get_layout()
         dev = self.current_device
         lib = _lib.load()
@@ -325,8 +325,13 @@ class _TBEBase(nn.Module):
                     "tbe_forward_nobag_f32",
                 )
                 return out
-            out_off, stride, shape = self._pooled_layout(B)
-            out = torch.empty(shape, dtype=torch.float32, device=dev)
+            if into is not None:
+                # caller-provided buffer + addressing (feat_out_offset, row stride): several lookups
+                # can fill disjoint column blocks of one [B, sum D] matrix without a cat
+                out, out_off, stride = into
+            else:
+                out_off, stride, shape = self._pooled_layout(B)
+                out = torch.empty(shape, dtype=torch.float32, device=dev)
             check(
                 lib.tbe_forward_pooled_f32(ptr(lay.feat_weights), ptr(lay.feat_D),
                                            ptr(out_off), ptr(lay.feat_rows), self.F, B,
@@ -371,7 +376,7 @@ class _TBEBase(nn.Module):
 
     def _backward_impl(self, grad_out, indices, offsets, per_sample_weights, B: int,
                        opt: OptimizerArgs, state0_override: Optional[torch.Tensor] = None,
-                       prepared=None) -> None:
+                       prepared=None, layout=None) -> None:
         lay = self._get_layout()
         dev = self.current_device
         lib = _lib.load()
@@ -381,7 +386,9 @@ class _TBEBase(nn.Module):
         grad_out = grad_out.contiguous()
         if grad_out.dtype != torch.float32:
             grad_out = grad_out.float()
-        if self.pooling_mode == PoolingMode.NONE:
+        if layout is not None:
+            out_off, stride = layout
+        elif self.pooling_mode == PoolingMode.NONE:
             out_off, stride = lay.feat_out_offset, grad_out.shape[1]
         else:
             out_off, stride, _ = self._pooled_layout(B)
@@ -419,6 +426,51 @@ class _TBEBase(nn.Module):
                                            ptr(self._errors()), stream_ptr(dev)),
                 "tbe_backward_fused_f32",
             )
+
+
+class _FusedLookupInto(torch.autograd.Function):
+    """Like _FusedLookup, but writes its column blocks into a caller-provided [B, stride] buffer."""
+
+    @staticmethod
+    def forward(ctx, out, placeholder, module, indices, offsets, per_sample_weights, B, out_off, stride, prepare):
+        ctx.module, ctx.B, ctx.layout = module, B, (out_off, stride)
+        ctx.save_for_backward(indices, offsets, per_sample_weights)
+        module._forward_impl(indices, offsets, per_sample_weights, B, into=(out, out_off, stride))
+        ctx.prepared = module._prepare_backward(indices, offsets, B) if prepare else None
+        ctx.mark_dirty(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        indices, offsets, psw = ctx.saved_tensors
+        module = ctx.module
+        module.iter += 1
+        module._backward_impl(grad_out, indices, offsets, psw, ctx.B, module._optimizer_struct(),
+                              prepared=ctx.prepared, layout=ctx.layout)
+        ctx.prepared = None
+        return (grad_out,) + (None,) * 9
+
+
+class _DenseLookupInto(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, out, weights, module, indices, offsets, per_sample_weights, B, out_off, stride):
+        ctx.module, ctx.B, ctx.layout = module, B, (out_off, stride)
+        ctx.save_for_backward(indices, offsets, per_sample_weights)
+        module._forward_impl(indices, offsets, per_sample_weights, B, into=(out, out_off, stride))
+        ctx.mark_dirty(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        indices, offsets, psw = ctx.saved_tensors
+        module = ctx.module
+        grad_w = torch.zeros_like(module.weights)
+        base = grad_w.data_ptr()
+        ptrs = [base + 4 * module.weights_offsets[t] for t in module.feature_table_map]
+        state0 = torch.tensor(ptrs, dtype=torch.int64).to(grad_w.device)
+        opt = OptimizerArgs(_OPT_DENSE_GRAD, 0.0, 0.0, 0.0, 0.0, 0.0, 1)
+        module._backward_impl(grad_out, indices, offsets, psw, ctx.B, opt, state0_override=state0, layout=ctx.layout)
+        return (grad_out, grad_w) + (None,) * 7
 
 
 class _FusedLookup(torch.autograd.Function):
@@ -602,6 +654,17 @@ class SplitTableBatchedEmbeddingBagsCodegen(_TBEBase):
         return _FusedLookup.apply(self.placeholder_autograd_tensor, self, indices, offsets,
                                   per_sample_weights, B, prepare)
 
+    def forward_into(self, out: torch.Tensor, out_offsets: torch.Tensor, row_stride: int, indices: torch.Tensor,
+                     offsets: torch.Tensor, per_sample_weights: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Pooled lookup whose feature blocks land at `out[b * row_stride + out_offsets[f] + d]` of the
+        given buffer (returned, marked dirty for autograd)."""
+        indices, offsets, per_sample_weights, B = self._check_inputs(indices, offsets, per_sample_weights)
+        mode = self.overlap_backward_sort
+        prepare = torch.is_grad_enabled() and (
+            mode in (True, "1") or (mode == "auto" and indices.numel() <= self.overlap_backward_sort_max_ids))
+        return _FusedLookupInto.apply(out, self.placeholder_autograd_tensor, self, indices, offsets,
+                                      per_sample_weights, B, out_offsets, int(row_stride), prepare)
+
 
 class _DenseLookup(torch.autograd.Function):
     @staticmethod
@@ -661,3 +724,9 @@ class DenseTableBatchedEmbeddingBagsCodegen(_TBEBase):
                 feature_requires_grad: Optional[torch.Tensor] = None) -> torch.Tensor:
         indices, offsets, per_sample_weights, B = self._check_inputs(indices, offsets, per_sample_weights)
         return _DenseLookup.apply(self.weights, self, indices, offsets, per_sample_weights, B)
+
+    def forward_into(self, out: torch.Tensor, out_offsets: torch.Tensor, row_stride: int, indices: torch.Tensor,
+                     offsets: torch.Tensor, per_sample_weights: Optional[torch.Tensor] = None) -> torch.Tensor:
+        indices, offsets, per_sample_weights, B = self._check_inputs(indices, offsets, per_sample_weights)
+        return _DenseLookupInto.apply(out, self.weights, self, indices, offsets, per_sample_weights, B, out_offsets,
+                                      int(row_stride))

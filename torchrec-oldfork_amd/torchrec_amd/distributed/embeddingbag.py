@@ -19,6 +19,10 @@ EmbeddingBagCollectionSharder (:489-515).  The data path is re-designed for xGMI
                                                                TW columns, sum RW partials in rank order)
   backward: recat copy + a2a / all-gather, grads / W           tbe_pooled_exchange_pack (x 1/W fused) + ONE a2a
 
+Tiny tables can be DATA_PARALLEL (replicated): a dense-gradient TBE looks them up for the local
+batch and writes straight into its columns of the output matrix (no exchange, no cat); their
+gradient is all-reduced by DDP like any dense parameter (sharding/dp_sharding.py in the reference).
+
 Forward issues the lookup and the a2a before the caller's dense work and waits afterwards
 (`forward()` returns an awaitable), so the exchange overlaps the bottom MLP; autograd replays
 the same overlap in reverse for the gradient exchange.
@@ -44,6 +48,13 @@ def set_gradient_division(val: bool) -> None:
     GRADIENT_DIVISION = val
 
 
+def _default_dp_tbe_factory(specs, ftm, pooling_mode, device):
+    from fbgemm_gpu.split_table_batched_embeddings_ops import DenseTableBatchedEmbeddingBagsCodegen
+
+    with torch.cuda.device(device):
+        return DenseTableBatchedEmbeddingBagsCodegen(list(specs), feature_table_map=ftm, pooling_mode=pooling_mode)
+
+
 def _default_tbe_factory(specs, ftm, pooling_mode, device, fused_params):
     from fbgemm_gpu.split_table_batched_embeddings_ops import (
         ComputeDevice, EmbeddingLocation, SplitTableBatchedEmbeddingBagsCodegen)
@@ -62,11 +73,12 @@ class SparseFeaturesDist:
     """What input_dist hands to compute (embedding_types.py `SparseFeatures`, after the a2a):
     ids in [src rank][local feature][sample] order + offsets for the local TBE."""
 
-    def __init__(self, values, offsets, weights, batch_size: int) -> None:
+    def __init__(self, values, offsets, weights, batch_size: int, dp=None) -> None:
         self.values, self.offsets, self.weights, self.batch_size = values, offsets, weights, batch_size
+        self.dp = dp  # (values, offsets, weights) of the data-parallel features, local batch
 
     def record_stream(self, stream) -> None:
-        for t in (self.values, self.offsets, self.weights):
+        for t in (self.values, self.offsets, self.weights) + (tuple(self.dp) if self.dp is not None else ()):
             if t is not None and t.is_cuda:
                 t.record_stream(stream)
 
@@ -198,6 +210,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
         fused_params: Optional[Dict[str, Any]] = None,
         device: Optional[torch.device] = None,
         tbe_factory: Optional[Callable] = None,
+        dp_tbe_factory: Optional[Callable] = None,
     ) -> None:
         super().__init__()
         self._env = env
@@ -226,7 +239,9 @@ class ShardedEmbeddingBagCollection(nn.Module):
         kind: List[int] = []  # per table: -1 row-wise, else owning rank
         for c in cfgs:
             ps = table_name_to_parameter_sharding[c.name]
-            if ps.sharding_type == ShardingType.ROW_WISE.value:
+            if ps.sharding_type == ShardingType.DATA_PARALLEL.value:
+                kind.append(-2)
+            elif ps.sharding_type == ShardingType.ROW_WISE.value:
                 kind.append(-1)
             elif ps.sharding_type == ShardingType.TABLE_WISE.value:
                 kind.append(int(ps.ranks[0]))
@@ -235,7 +250,9 @@ class ShardedEmbeddingBagCollection(nn.Module):
                                           "(table_wise / row_wise)")
         self._table_kind = kind
         # local feature list of every rank: row-wise features first (same columns on every rank)
-        rw_feats = [g for g in range(Fg) if kind[g_table[g]] < 0]
+        rw_feats = [g for g in range(Fg) if kind[g_table[g]] == -1]
+        self._dp_feats = [g for g in range(Fg) if kind[g_table[g]] == -2]
+        self._sharded_feats = [g for g in range(Fg) if kind[g_table[g]] != -2]
         local_feats = [rw_feats + [g for g in range(Fg) if kind[g_table[g]] == r] for r in range(W)]
         self._local_feats = local_feats
         self._D_local_per_rank = [sum(g_dim[g] for g in lf) for lf in local_feats]
@@ -248,14 +265,17 @@ class ShardedEmbeddingBagCollection(nn.Module):
         for r in range(W):
             col = 0
             for g in local_feats[r]:
-                if kind[g_table[g]] < 0:
+                if kind[g_table[g]] == -1:
                     feat_src[g], feat_slab_col[g] = -1, col
                 elif kind[g_table[g]] == r:
                     feat_src[g], feat_slab_col[g] = r, col
                 col += g_dim[g]
+        for g in self._dp_feats:
+            feat_src[g] = -2
         out_col = [0]
         for d in g_dim:
             out_col.append(out_col[-1] + d)
+        self._out_col = out_col
         dev = self._device
         self._feat_out_col = torch.tensor(out_col, dtype=torch.int32, device=dev)
         self._feat_src = torch.tensor(feat_src, dtype=torch.int32, device=dev)
@@ -272,7 +292,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
             if t in local_table_index:
                 continue
             c = cfgs[t]
-            if kind[t] < 0:
+            if kind[t] == -1:
                 rows = rw_shard_rows(c.num_embeddings, W)[me]
                 self._local_tables.append(_LocalTable(c, rows, me * rw_block_size(c.num_embeddings, W), True))
             else:
@@ -295,6 +315,22 @@ class ShardedEmbeddingBagCollection(nn.Module):
             self._optim = EmbeddingFusedOptimizer(self._emb_module, [lt.cfg.name for lt in self._local_tables])
         else:
             self._optim = None
+        # global-column addressing of the sharded features for the world_size == 1 "write into one buffer" path
+        self._sharded_out_off = torch.tensor([out_col[g] for g in local_feats[me]], dtype=torch.int64, device=dev)
+        # ---- data-parallel (replicated) tables -------------------------------------------------------
+        self._dp_module = None
+        self._dp_table_ids: List[int] = []
+        if self._dp_feats:
+            for g in self._dp_feats:
+                if g_table[g] not in self._dp_table_ids:
+                    self._dp_table_ids.append(g_table[g])
+            dp_ftm = [self._dp_table_ids.index(g_table[g]) for g in self._dp_feats]
+            dpf = dp_tbe_factory or _default_dp_tbe_factory
+            self._dp_module = dpf([(cfgs[t].num_embeddings, cfgs[t].embedding_dim) for t in self._dp_table_ids], dp_ftm,
+                                  pooling_type_to_pooling_mode(cfgs[0].pooling), dev)
+            for t, w in zip(self._dp_table_ids, self._dp_module.split_embedding_weights()):
+                w.uniform_(cfgs[t].get_weight_init_min(), cfgs[t].get_weight_init_max())
+            self._dp_out_off = torch.tensor([out_col[g] for g in self._dp_feats], dtype=torch.int64, device=dev)
 
     # ---- parameters -----------------------------------------------------------------------------
     def _init_parameters(self) -> None:
@@ -324,8 +360,18 @@ class ShardedEmbeddingBagCollection(nn.Module):
             destination[f"{prefix}embedding_bags.{name}.weight"] = w  # key as embeddingbag.py:416
         return destination
 
+    def dp_tables(self) -> Dict[str, torch.Tensor]:
+        """table name -> replicated weight [rows, D] (a view of the dense TBE's parameter)."""
+        if self._dp_module is None:
+            return {}
+        return {self._embedding_bag_configs[t].name: w
+                for t, w in zip(self._dp_table_ids, self._dp_module.split_embedding_weights())}
+
     def named_parameters(self, prefix: str = "", recurse: bool = True) -> Iterator[Tuple[str, nn.Parameter]]:
-        yield from ()  # fused: weights are updated inside backward (batched_embedding_kernel.py:655-658)
+        # sharded tables are fused (updated inside backward, batched_embedding_kernel.py:655-658);
+        # replicated tables are ordinary dense parameters (all-reduced by DDP, stepped by the dense optimizer)
+        if self._dp_module is not None:
+            yield (prefix + ("." if prefix else "") + "_dp_module.weights", self._dp_module.weights)
 
     # ---- layouts --------------------------------------------------------------------------------
     def _exchange_layout(self, B: int) -> Dict[str, Any]:
@@ -360,11 +406,42 @@ class ShardedEmbeddingBagCollection(nn.Module):
             self._kjt_cache[ck] = hit
         return hit
 
+    def _dp_inputs(self, features: KeyedJaggedTensor):
+        """ids of the replicated features for the LOCAL batch (no communication)."""
+        if self._dp_module is None:
+            return None
+        keys = features.keys()
+        ck = ("dp", tuple(keys))
+        hit = self._kjt_cache.get(ck)
+        if hit is None:
+            pos = {k: i for i, k in enumerate(keys)}
+            order = [pos[self._feature_names[g]] for g in self._dp_feats]
+            hit = (order, torch.tensor(order, dtype=torch.int64, device=self._device))
+            self._kjt_cache[ck] = hit
+        order, order_t = hit
+        B = features.stride()
+        fixed = features.fixed_lengths()
+        weights = features.weights_or_none() if self._is_weighted else None
+        if fixed is not None and len(set(fixed)) == 1 and fixed[0] > 0:
+            L = fixed[0]
+            nkeys = len(keys)
+            v = features.values().view(nkeys, B * L).index_select(0, order_t).view(-1)
+            w = weights.view(nkeys, B * L).index_select(0, order_t).view(-1) if weights is not None else None
+            ck2 = ("dpoff", B, L)
+            offs = self._kjt_cache.get(ck2)
+            if offs is None:
+                offs = torch.arange(len(order) * B + 1, dtype=torch.int64, device=self._device) * L
+                self._kjt_cache[ck2] = offs
+            return v, offs, w
+        sub = features.permute(order, None)
+        return sub.values(), sub.offsets().long(), (sub.weights_or_none() if weights is not None else None)
+
     def input_dist(self, features: KeyedJaggedTensor) -> Awaitable[SparseFeaturesDist]:
         W, B = self._world_size, features.stride()
         order, order_t = self._send_perm(features.keys())
         fixed = features.fixed_lengths()
         weights = features.weights_or_none() if self._is_weighted else None
+        dp_in = self._dp_inputs(features)
         if fixed is not None and len(set(fixed)) == 1 and fixed[0] > 0:
             L = fixed[0]
             nkeys = len(features.keys())
@@ -395,7 +472,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
                 if offsets is None:
                     offsets = torch.arange(W * self._F_local * B + 1, dtype=torch.int64, device=self._device) * L
                     self._kjt_cache[ck] = offsets
-                return SparseFeaturesDist(vals, offsets, recv_w, B)
+                return SparseFeaturesDist(vals, offsets, recv_w, B, dp_in)
 
             return _InputDistAwaitable(finish)
         # ---- data-dependent pooling factors: lengths a2a, D2H of the value counts, values a2a
@@ -436,23 +513,39 @@ class ShardedEmbeddingBagCollection(nn.Module):
                     self._row_base.view(1, -1).expand(W, -1).reshape(-1),
                     recv_l.view(W * self._F_local, B).sum(dim=1).long())
                 vals = recv_v - seg
-            return SparseFeaturesDist(vals, offsets, recv_w, B)
+            return SparseFeaturesDist(vals, offsets, recv_w, B, dp_in)
 
         return _InputDistAwaitable(finish_var)
 
     # ---- compute + output dist ------------------------------------------------------------------
+    def _dp_fill(self, out: torch.Tensor, dist_input: SparseFeaturesDist) -> torch.Tensor:
+        if self._dp_module is None:
+            return out
+        v, offs, w = dist_input.dp
+        return self._dp_module.forward_into(out, self._dp_out_off, self._D_total, v, offs, w)
+
     def compute_and_output_dist(self, dist_input: SparseFeaturesDist) -> Awaitable[KeyedTensor]:
         B = dist_input.batch_size
         keys, lpe = self._feature_names, self._lengths_per_embedding
+        if self._world_size == 1:
+            if self._dp_module is None:
+                emb = self._emb_module(dist_input.values, dist_input.offsets, dist_input.weights)
+                return NoWait(KeyedTensor(keys, lpe, emb))
+            # both lookups write their column blocks of ONE [B, sum D] matrix
+            out = torch.empty((B, self._D_total), dtype=torch.float32, device=self._device)
+            if self._emb_module is not None:
+                out = self._emb_module.forward_into(out, self._sharded_out_off, self._D_total, dist_input.values,
+                                                    dist_input.offsets, dist_input.weights)
+            return NoWait(KeyedTensor(keys, lpe, self._dp_fill(out, dist_input)))
         if self._emb_module is not None:
             emb = self._emb_module(dist_input.values, dist_input.offsets, dist_input.weights)
         else:
-            emb = torch.zeros((self._world_size * B, 0), dtype=torch.float32, device=self._device)
-        if self._world_size == 1:
-            return NoWait(KeyedTensor(keys, lpe, emb))
+            emb = torch.zeros((self._world_size * B, 0), dtype=torch.float32, device=self._device,
+                              requires_grad=True)
         state = _ExchangeState(self, B)
         recv = _ExchangeReq.apply(emb, state)
-        return _OutputAwaitable(lambda: KeyedTensor(keys, lpe, _ExchangeWait.apply(recv, state)))
+        return _OutputAwaitable(
+            lambda: KeyedTensor(keys, lpe, self._dp_fill(_ExchangeWait.apply(recv, state), dist_input)))
 
     def forward(self, features: KeyedJaggedTensor) -> Awaitable[KeyedTensor]:
         return self.compute_and_output_dist(self.input_dist(features).wait())
@@ -462,13 +555,16 @@ class EmbeddingBagCollectionSharder:
     """Builds the sharded module from an EmbeddingBagCollection + per-table plan
     (torchrec/distributed/embeddingbag.py:489-515)."""
 
-    def __init__(self, fused_params: Optional[Dict[str, Any]] = None, tbe_factory: Optional[Callable] = None) -> None:
+    def __init__(self, fused_params: Optional[Dict[str, Any]] = None, tbe_factory: Optional[Callable] = None,
+                 dp_tbe_factory: Optional[Callable] = None) -> None:
         self.fused_params = fused_params
         self.tbe_factory = tbe_factory
+        self.dp_tbe_factory = dp_tbe_factory
 
     def shard(self, module: EmbeddingBagCollection, params: Dict[str, ParameterSharding], env: ShardingEnv,
               device: Optional[torch.device] = None) -> ShardedEmbeddingBagCollection:
-        return ShardedEmbeddingBagCollection(module, params, env, self.fused_params, device, self.tbe_factory)
+        return ShardedEmbeddingBagCollection(module, params, env, self.fused_params, device, self.tbe_factory,
+                                             self.dp_tbe_factory)
 
     @property
     def module_type(self):

@@ -68,7 +68,8 @@ class DistributedModelParallel(nn.Module):
                     for n, _ in nn.Module.named_buffers(sub):
                         ignore.append(f"{path}.{n}" if path else n)
                     for n, _ in nn.Module.named_parameters(sub):
-                        ignore.append(f"{path}.{n}" if path else n)
+                        if not n.startswith("_dp_module."):  # replicated tables ARE reduced by DDP
+                            ignore.append(f"{path}.{n}" if path else n)
             DistributedDataParallel._set_params_and_buffers_to_ignore_for_model(m, ignore)
             self._dmp_wrapped_module = DistributedDataParallel(
                 m, device_ids=[self.device.index] if self.device.type == "cuda" else None,

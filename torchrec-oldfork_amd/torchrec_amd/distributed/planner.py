@@ -6,13 +6,19 @@ perf constants are A100-era (planner/constants.py:14-73: HBM 32 GiB / 897 GB/s, 
 600 GB/s); these are MI355X's (288 GB HBM3E, ~6.3 TB/s achievable, 7 xGMI links x ~153 GB/s,
 all-to-all uses every link at once).
 
-Cost model per (table, rank): a pooled lookup moves B_global * L * D * 4 bytes from HBM and
-B_global * D * 4 bytes over xGMI regardless of the table's row count, so balancing the NUMBER
-of (feature, dim) units per rank balances both.  Table-wise placement is a greedy
-longest-processing-time fill (as planner/partitioners.py:181-197 does by perf); because F tables
-rarely divide evenly over W ranks, the `F mod W` largest tables are row-wise sharded — every
-rank then carries exactly the same lookup volume — which is also what spreads the tables that
-would not fit one HBM.
+Cost model.  Per step and per sharded (table-wise) feature the owner sends B_local * D * 4 bytes to
+every peer over that peer's own xGMI link; the slowest link decides, so the plan minimises the
+MAXIMUM number of (feature, dim) units any rank owns.  Three levers, in this order:
+  * data-parallel (replicated) tiny tables: a table of R rows costs an all-reduce of R * D * 4 bytes
+    of dense gradient instead of B_local * D * 4 bytes per link and direction; below ~2.5 K rows
+    (11 of the 26 Criteo tables, 2.5 MB in total) that is a clear win and removes 42 % of the
+    exchanged bytes (the reference offers the same choice as ShardingType.DATA_PARALLEL,
+    sharding/dp_sharding.py);
+  * table-wise placement of the rest by a greedy longest-processing-time fill
+    (planner/partitioners.py:181-197 does this by estimated perf);
+  * row-wise only where a table does not fit one GPU's HBM (or on request): with pooled output a
+    row-wise feature makes EVERY rank send a partial pool to every peer, W x the bytes of a
+    table-wise feature, so it is a capacity tool here, not a balancing tool.
 """
 from dataclasses import dataclass
 from typing import Dict, List, Optional
@@ -49,10 +55,11 @@ def rw_shard_rows(rows: int, world_size: int) -> List[int]:
 
 class EmbeddingShardingPlanner:
     def __init__(self, topology: Topology, constraints: Optional[Dict[str, List[str]]] = None,
-                 num_row_wise: Optional[int] = None) -> None:
+                 num_row_wise: Optional[int] = None, dp_max_rows: int = 2500) -> None:
         self.topology = topology
         self.constraints = constraints or {}
         self.num_row_wise = num_row_wise
+        self.dp_max_rows = dp_max_rows
 
     def plan_tables(self, tables: List[EmbeddingBagConfig]) -> Dict[str, ParameterSharding]:
         W = self.topology.world_size
@@ -61,23 +68,34 @@ class EmbeddingShardingPlanner:
         by_size = sorted(tables, key=lambda t: (-size[t.name], t.name))
         forced_rw = {n for n, c in self.constraints.items() if c == [ShardingType.ROW_WISE.value]}
         forced_tw = {n for n, c in self.constraints.items() if c == [ShardingType.TABLE_WISE.value]}
-        n_rw = self.num_row_wise if self.num_row_wise is not None else (len(tables) % W if W > 1 else 0)
+        forced_dp = {n for n, c in self.constraints.items() if c == [ShardingType.DATA_PARALLEL.value]}
+        dp = set(forced_dp)
+        if W > 1:
+            for t in tables:
+                if t.num_embeddings <= self.dp_max_rows and t.name not in forced_rw and t.name not in forced_tw:
+                    dp.add(t.name)
+        n_rw = self.num_row_wise if self.num_row_wise is not None else 0
         rw = set(forced_rw)
         for t in by_size:
-            if W > 1 and size[t.name] > cap:
+            if W > 1 and size[t.name] > cap and t.name not in dp:
                 rw.add(t.name)  # does not fit one GPU
         for t in by_size:
             if len(rw) >= max(n_rw, len(forced_rw)) or W == 1:
                 break
-            if t.name not in forced_tw:
+            if t.name not in forced_tw and t.name not in dp:
                 rw.add(t.name)
         # greedy longest-processing-time fill of the table-wise tables
         units = [0.0] * W
         mem = [sum(rw_shard_rows(t.num_embeddings, W)[r] * t.embedding_dim * 4 for t in tables if t.name in rw)
-               for r in range(W)]
+               + sum(size[t.name] for t in tables if t.name in dp) for r in range(W)]
         out: Dict[str, ParameterSharding] = {}
         kernel = EmbeddingComputeKernel.BATCHED_FUSED.value
         for t in by_size:
+            if t.name in dp:
+                out[t.name] = ParameterSharding(
+                    ShardingType.DATA_PARALLEL.value, EmbeddingComputeKernel.BATCHED_DENSE.value, list(range(W)),
+                    [ShardMetadata([0, 0], [t.num_embeddings, t.embedding_dim], f"rank:{r}/cuda:{r}") for r in range(W)])
+                continue
             if t.name in rw:
                 rows = rw_shard_rows(t.num_embeddings, W)
                 off = 0
