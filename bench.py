@@ -106,7 +106,8 @@ def main():
         model.fused_optimizer,
         KeyedOptimizerWrapper(dense_params, lambda p: torch.optim.SGD(p, lr=args.lr))])
     plan = model.plan
-    n_rw = sum(1 for p in next(iter(plan.plan.values())).values() if p.sharding_type == "row_wise")
+    kinds = [p.sharding_type for p in next(iter(plan.plan.values())).values()]
+    n_rw, n_dp = kinds.count("row_wise"), kinds.count("data_parallel")
 
     data = RandomRecDataset(DEFAULT_CAT_NAMES, B_local, rows, ids_per_feature=1, num_dense=INT_FEATURE_COUNT,
                             manual_seed=1234 + rank, num_generated_batches=args.num_batches, device=dev,
@@ -144,9 +145,13 @@ def main():
     # ---- roofline of the dominant embedding kernel (this rank's launches) ---------------------------
     # Units per launch on this rank: every TBE launch covers the GLOBAL batch for the features this
     # rank holds (table-wise: whole features; row-wise: 1/W of a feature's rows => 1/W of its bytes).
+    # At N > 1 a rank runs TWO lookups per step (the fused one over the global batch for its sharded
+    # features, the dense-gradient one over its LOCAL batch for the replicated tiny tables); the
+    # profile slots hold both, so everything below is per STEP: summed launch time, summed bytes.
     shard = model.sharded_modules()[0]
-    feat_units = sum((1.0 / world) if shard._table_kind[i] < 0 else (1.0 if shard._table_kind[i] == rank else 0.0)
-                     for i in range(F))
+    kind = shard._table_kind  # -2 replicated, -1 row-wise, >= 0 owning rank
+    feat_units = sum((1.0 / world) if kind[i] == -1 else (1.0 if kind[i] == rank else 0.0) for i in range(F))
+    feat_units += sum(1.0 for i in range(F) if kind[i] == -2) / world  # local batch = 1/W of the global batch
     # Algorithmic bytes per launch (SURVEY.md §8d general formula, L = 1, fp32 rows, int64 ids):
     #   forward : units * B * (D*4 row + 8 id + 8 offset + D*4 output)
     #   backward: units * B * (D*4 grad + 16 ids) + U_launch * 2*D*4   (row read + row write per DISTINCT row)
@@ -156,8 +161,7 @@ def main():
     # F*L rows would credit the kernel with bytes it never moves (it did read > 100 % of peak that way).
     rows_upd = ctypes.c_int64(0)
     lib.tbe_profile_read_rows(ctypes.byref(rows_upd))
-    n_bwd = max(prof[1][1], 1)
-    U_launch = rows_upd.value / n_bwd
+    U_launch = rows_upd.value / max(args.steps, 1)  # distinct rows per step on this rank
     fwd_bytes = feat_units * args.global_batch * (D * 4 + 8 + 8 + D * 4)
     bwd_bytes = feat_units * args.global_batch * (D * 4 + 16) + U_launch * 2 * D * 4
     bwd_bytes_all_distinct = feat_units * args.global_batch * (D * 4 + 16 + 2 * D * 4)
@@ -167,7 +171,7 @@ def main():
                                ("tbe_backward_prepare(linearize+sort, side stream)", 3, 0.0)):
         tot_ms, n = prof[slot]
         if n:
-            avg_ms = tot_ms / n
+            avg_ms = tot_ms / max(args.steps, 1)  # per step (one launch per step at N = 1)
             kern[name] = {"avg_us": avg_ms * 1e3, "launches": n, "algorithmic_MB": nbytes / 1e6,
                           "GB/s": nbytes / (avg_ms * 1e-3) / 1e9}
     dom = max((k for k in kern if not k.startswith("tbe_backward_")), key=lambda k: kern[k]["avg_us"], default=None)
@@ -212,7 +216,8 @@ def main():
             "config": {"workload": "DLRM Criteo-1TB shape: 26 tables (177.9M rows, 84.85 GiB fp32, D=128), 13 dense, "
                                    "pooling factor 1, dense 512-256-128, over 1024-1024-512-256-1, fused exact SGD",
                        "global_batch": args.global_batch, "local_batch": B_local,
-                       "parallelism": f"mp{world}: {F - n_rw} table-wise + {n_rw} row-wise tables, dense dp{world}",
+                       "parallelism": (f"mp{world}: {F - n_rw - n_dp} table-wise + {n_rw} row-wise + {n_dp} replicated "
+                                       f"(data-parallel) tables, dense dp{world}"),
                        "ids": f"zipf({args.zipf})" if args.zipf else "uniform", "row_cap": args.row_cap or None},
             "roofline": roofline, "cpu_baseline": cpu,
         }
