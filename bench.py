@@ -80,9 +80,15 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if world > 1:
+    # TORCHREC_AMD_FORCE_EXCHANGE=1: rehearsal of the N > 1 data path on one GPU (a one-rank RCCL group)
+    rehearse = world == 1 and os.environ.get("TORCHREC_AMD_FORCE_EXCHANGE") == "1"
+    if world > 1 or rehearse:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29517")
+        if rehearse:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         env = ShardingEnv.from_process_group(dist.group.WORLD)
     else:
         env = ShardingEnv.from_local(1, 0)
@@ -222,7 +228,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -1,0 +1,330 @@
+"""GPU rehearsal of the N > 1 path on a ONE-GPU box (the pool has no multi-GPU box for this author):
+
+* world_size 2, both ranks on cuda:0, `gloo` process group: real HIP TBE (a2a-ready output layout,
+  row-wise masking through the bounds check), real exchange unpack / pack kernels, real dense-gradient
+  TBE for the replicated tables, DDP on device tensors.  gloo has no device all-to-all, so the test
+  stages `all_to_all_single` through host memory — that is test plumbing around the product path.
+* world_size 1 on RCCL (`nccl` backend) with the exchange forced on: the asynchronous id / pooled
+  all-to-all, their stream hand-over and the exchange kernels run through the real RCCL
+  ProcessGroup.
+
+Checks follow the reference's sharded-vs-unsharded pattern
+(torchrec/distributed/test_utils/test_model_parallel_base.py:148-294).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import _paths  # noqa: F401
+from test_sharded_gloo import _free_port
+
+pytestmark = pytest.mark.gpu
+
+ROWS = [5000, 7, 230, 90000, 5, 1201]
+D = 128
+LR = 0.25
+B_LOCAL = 48
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
+def _stage_a2a_through_host():
+    real = dist.all_to_all_single
+
+    def a2a(output, input, output_split_sizes=None, input_split_sizes=None, group=None, async_op=False):
+        if not input.is_cuda:
+            return real(output, input, output_split_sizes, input_split_sizes, group=group, async_op=async_op)
+        torch.cuda.current_stream().synchronize()
+        o = torch.empty(output.shape, dtype=output.dtype)
+        real(o, input.cpu().contiguous(), output_split_sizes, input_split_sizes, group=group)
+        output.copy_(o)
+        return _Done() if async_op else None
+
+    dist.all_to_all_single = a2a
+
+
+def _data(W, fixed_len, weighted, seed=11):
+    rng = np.random.default_rng(seed)
+    F = len(ROWS)
+    per_rank = []
+    for _ in range(W):
+        lengths = (np.full(F * B_LOCAL, fixed_len) if fixed_len else rng.integers(0, 4, size=F * B_LOCAL)).astype(np.int32)
+        vals = np.concatenate([rng.integers(0, ROWS[f], size=int(lengths[f * B_LOCAL:(f + 1) * B_LOCAL].sum()))
+                               for f in range(F)]).astype(np.int64)
+        wts = (rng.random(vals.size).astype(np.float32) + 0.5) if weighted else None
+        grad = rng.standard_normal((B_LOCAL, F * D)).astype(np.float32)
+        per_rank.append((lengths, vals, wts, grad))
+    init = [rng.standard_normal((r, D)).astype(np.float32) for r in ROWS]
+    return per_rank, init
+
+
+def _build_sharded(W, backend_env, weighted, n_rw, dp_max_rows):
+    from torchrec_amd.distributed.embeddingbag import ShardedEmbeddingBagCollection
+    from torchrec_amd.distributed.planner import EmbeddingShardingPlanner, Topology
+    from torchrec_amd.modules.embedding_configs import EmbeddingBagConfig
+    from torchrec_amd.modules.embedding_modules import EmbeddingBagCollection
+
+    keys = [f"f{i}" for i in range(len(ROWS))]
+    tables = [EmbeddingBagConfig(name=f"t{i}", embedding_dim=D, num_embeddings=ROWS[i], feature_names=[keys[i]])
+              for i in range(len(ROWS))]
+    ebc = EmbeddingBagCollection(tables, is_weighted=weighted, device=torch.device("meta"))
+    plan = EmbeddingShardingPlanner(Topology(W), num_row_wise=n_rw, dp_max_rows=dp_max_rows).plan_tables(tables)
+    sebc = ShardedEmbeddingBagCollection(ebc, plan, backend_env, {"learning_rate": LR}, torch.device("cuda", 0))
+    return keys, plan, sebc
+
+
+def _run_rank(sebc, keys, per_rank, init, rank, W, fixed_len, weighted):
+    from torchrec_amd.sparse.jagged_tensor import KeyedJaggedTensor
+
+    dev = torch.device("cuda", 0)
+    for name, (w, row0) in sebc.local_shards().items():
+        w.copy_(torch.from_numpy(init[int(name[1:])][row0:row0 + w.shape[0]]))
+    with torch.no_grad():
+        for name, w in sebc.dp_tables().items():
+            w.copy_(torch.from_numpy(init[int(name[1:])]))
+    lengths, vals, wts, grad = per_rank[rank]
+    wt = torch.from_numpy(wts).to(dev) if weighted else None
+    if fixed_len:
+        kjt = KeyedJaggedTensor.from_fixed_lengths(keys, torch.from_numpy(vals).to(dev), [fixed_len] * len(keys), weights=wt)
+    else:
+        kjt = KeyedJaggedTensor.from_lengths_sync(keys, torch.from_numpy(vals).to(dev), torch.from_numpy(lengths).to(dev),
+                                                  weights=wt)
+    out = sebc(kjt).wait()
+    vals_out = out.values()
+    vals_out.backward(torch.from_numpy(grad).to(dev))
+    torch.cuda.synchronize()
+    shards = {n: (w.detach().cpu().numpy().copy(), r0) for n, (w, r0) in sebc.local_shards().items()}
+    if sebc._dp_module is not None:
+        g = sebc._dp_module.weights.grad.detach().clone()
+        if W > 1:
+            gc = g.cpu()
+            dist.all_reduce(gc)
+            g = gc.to(dev)
+        g /= W
+        with torch.no_grad():
+            sebc._dp_module.weights -= LR * g
+        for n, w in sebc.dp_tables().items():
+            shards[n] = (w.detach().cpu().numpy().copy(), 0)
+    return vals_out.detach().cpu().numpy().copy(), shards
+
+
+def _worker(rank, W, port, fixed_len, weighted, n_rw, dp_max_rows, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=W)
+    try:
+        _stage_a2a_through_host()
+        from torchrec_amd.distributed.types import ShardingEnv
+
+        per_rank, init = _data(W, fixed_len, weighted)
+        keys, plan, sebc = _build_sharded(W, ShardingEnv.from_process_group(dist.group.WORLD), weighted, n_rw, dp_max_rows)
+        out, shards = _run_rank(sebc, keys, per_rank, init, rank, W, fixed_len, weighted)
+        ret[rank] = (out, shards, {n: p.sharding_type for n, p in plan.items()})
+    finally:
+        dist.destroy_process_group()
+
+
+def _check_against_oracle(ret, W, fixed_len, weighted, n_rw, dp_max_rows):
+    from oracle import oracle
+
+    per_rank, init = _data(W, fixed_len, weighted)
+    F, B = len(ROWS), B_LOCAL
+    tabs = oracle.Tables(ROWS, [D] * F)
+    for t in range(F):
+        tabs.weights[t][...] = init[t]
+    for r in range(W):
+        lengths, vals, wts, _ = per_rank[r]
+        offs = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+        ref, _ = oracle.tbe_forward(tabs, vals, offs, wts)
+        if fixed_len == 1 and not weighted:
+            np.testing.assert_array_equal(ret[r][0], ref)  # pure gather: bit-exact through the whole exchange
+        else:
+            np.testing.assert_allclose(ret[r][0], ref, rtol=1e-5, atol=1e-5)
+    kinds = ret[0][2]
+    assert sum(1 for k in kinds.values() if k == "row_wise") == n_rw
+    assert sum(1 for k in kinds.values() if k == "data_parallel") == (sum(1 for r in ROWS if r <= dp_max_rows) if W > 1 else 0)
+    g_len = np.concatenate([np.concatenate([per_rank[r][0][f * B:(f + 1) * B] for r in range(W)]) for f in range(F)])
+    pos = [np.concatenate([[0], np.cumsum(per_rank[r][0])]) for r in range(W)]
+    cat = lambda i: np.concatenate([np.concatenate([per_rank[r][i][pos[r][f * B]:pos[r][(f + 1) * B]]  # noqa: E731
+                                                    for r in range(W)]) for f in range(F)])
+    g_vals, g_w = cat(1), (cat(2) if weighted else None)
+    g_grad = np.concatenate([per_rank[r][3] for r in range(W)], axis=0) / W
+    g_offs = np.concatenate([[0], np.cumsum(g_len)]).astype(np.int64)
+    oracle.tbe_backward(tabs, g_vals, g_offs, g_grad, oracle.OPT_EXACT_SGD, LR, g_w)
+    seen = {t: 0 for t in range(F)}
+    for r in range(W):
+        for name, (w, row0) in ret[r][1].items():
+            t = int(name[1:])
+            np.testing.assert_allclose(w, tabs.weights[t][row0:row0 + w.shape[0]], rtol=2e-5, atol=2e-5)
+            seen[t] += w.shape[0]
+    for t in range(F):
+        assert seen[t] == ROWS[t] * (W if kinds[f"t{t}"] == "data_parallel" else 1)
+
+
+@pytest.mark.parametrize("fixed_len,weighted,n_rw,dp_max_rows", [
+    (1, False, 0, 0), (1, False, 2, 10), (2, True, 1, 0), (0, False, 1, 10), (0, True, 6, 0)])
+def test_sharded_world2_on_one_gpu(fixed_len, weighted, n_rw, dp_max_rows):
+    W = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(W, _free_port(), fixed_len, weighted, n_rw, dp_max_rows, ret), nprocs=W, join=True)
+    _check_against_oracle(ret, W, fixed_len, weighted, n_rw, dp_max_rows)
+
+
+def _rccl_worker(rank, port, fixed_len, weighted, dp_max_rows, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        import torchrec_amd.distributed.embeddingbag as eb
+        from torchrec_amd.distributed.types import ShardingEnv
+
+        eb.FORCE_EXCHANGE = True
+        per_rank, init = _data(1, fixed_len, weighted)
+        keys, plan, sebc = _build_sharded(1, ShardingEnv.from_process_group(dist.group.WORLD), weighted, 0, dp_max_rows)
+        assert sebc._exchange
+        out, shards = _run_rank(sebc, keys, per_rank, init, 0, 1, fixed_len, weighted)
+        ret[0] = (out, shards, {n: p.sharding_type for n, p in plan.items()})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fixed_len,weighted,dp_max_rows", [(1, False, 10), (0, True, 0)])
+def test_exchange_through_rccl_world1(fixed_len, weighted, dp_max_rows):
+    """The asynchronous id + pooled all-to-all and the exchange kernels over a real RCCL group."""
+    ret = mp.Manager().dict()
+    mp.spawn(_rccl_worker, args=(_free_port(), fixed_len, weighted, dp_max_rows, ret), nprocs=1, join=True)
+    _check_against_oracle(ret, 1, fixed_len, weighted, 0, dp_max_rows)
+
+
+# ---- full DLRM train loop: 2 ranks on one GPU == 1 rank on the global batch -------------------------
+
+E_ROWS = [3000, 9, 31000, 170, 8, 5, 999]
+E_B = 64  # per rank
+E_STEPS = 4
+E_LR = 0.05
+
+
+def _e2e_batches(W):
+    rng = np.random.default_rng(5)
+    out = []
+    for _ in range(E_STEPS + 2):
+        dense = rng.standard_normal((W * E_B, 13)).astype(np.float32)
+        ids = np.stack([rng.integers(0, r, size=W * E_B) for r in E_ROWS]).astype(np.int64)  # [F, W*B]
+        labels = rng.integers(0, 2, size=W * E_B).astype(np.int64)
+        out.append((dense, ids, labels))
+    return out
+
+
+def _e2e_model(env, dev, dp_max_rows):
+    from torchrec_amd.distributed.embeddingbag import EmbeddingBagCollectionSharder
+    from torchrec_amd.distributed.model_parallel import DistributedModelParallel
+    from torchrec_amd.distributed.planner import EmbeddingShardingPlanner, Topology
+    from torchrec_amd.models.dlrm import DLRMTrain
+    from torchrec_amd.modules.embedding_configs import EmbeddingBagConfig
+    from torchrec_amd.modules.embedding_modules import EmbeddingBagCollection
+    from torchrec_amd.optim.keyed import CombinedOptimizer, KeyedOptimizerWrapper
+
+    torch.manual_seed(0)
+    keys = [f"c{i}" for i in range(len(E_ROWS))]
+    tables = [EmbeddingBagConfig(name=f"t{i}", embedding_dim=D, num_embeddings=E_ROWS[i], feature_names=[keys[i]])
+              for i in range(len(E_ROWS))]
+    ebc = EmbeddingBagCollection(tables, device=torch.device("meta"))
+    tm = DLRMTrain(ebc, 13, [64, D], [96, 32, 1], dense_device=dev)
+    model = DistributedModelParallel(tm, env=env, device=dev, sharders=[EmbeddingBagCollectionSharder({"learning_rate": E_LR})],
+                                     planner=EmbeddingShardingPlanner(Topology(env.world_size), num_row_wise=1,
+                                                                      dp_max_rows=dp_max_rows))
+    opt = CombinedOptimizer([model.fused_optimizer,
+                             KeyedOptimizerWrapper(dict(model.named_parameters()), lambda p: torch.optim.SGD(p, lr=E_LR))])
+    return keys, model, opt
+
+
+def _e2e_init_tables(model):
+    s = model.sharded_modules()[0]
+    for name, (w, row0) in s.local_shards().items():
+        t = int(name[1:])
+        full = np.random.default_rng(900 + t).standard_normal((E_ROWS[t], D)).astype(np.float32) * 0.1
+        w.copy_(torch.from_numpy(full[row0:row0 + w.shape[0]]))
+    with torch.no_grad():
+        for name, w in s.dp_tables().items():
+            t = int(name[1:])
+            w.copy_(torch.from_numpy(np.random.default_rng(900 + t).standard_normal((E_ROWS[t], D)).astype(np.float32) * 0.1))
+
+
+def _e2e_run(model, opt, keys, batches, rank, W, dev):
+    from torchrec_amd.datasets.random import Batch
+    from torchrec_amd.distributed.train_pipeline import TrainPipelineSparseDist
+    from torchrec_amd.sparse.jagged_tensor import KeyedJaggedTensor
+
+    sl = slice(rank * E_B, (rank + 1) * E_B) if W > 1 else slice(None)
+    bl = [Batch(torch.from_numpy(d[sl]).to(dev),
+                KeyedJaggedTensor.from_fixed_lengths(keys, torch.from_numpy(np.ascontiguousarray(i[:, sl]).reshape(-1)).to(dev),
+                                                     [1] * len(keys)),
+                torch.from_numpy(lab[sl]).to(dev)) for d, i, lab in batches]
+    pipe = TrainPipelineSparseDist(model, opt, dev)
+    model.train()
+    it = iter(bl)
+    losses = []
+    for _ in range(E_STEPS):
+        loss, _ = pipe.progress(it)
+        losses.append(float(loss))
+    torch.cuda.synchronize()
+    s = model.sharded_modules()[0]
+    tabs = {n: (w.detach().cpu().numpy().copy(), r0) for n, (w, r0) in s.local_shards().items()}
+    for n, w in s.dp_tables().items():
+        tabs[n] = (w.detach().cpu().numpy().copy(), 0)
+    dense = {k: v.detach().cpu().numpy().copy() for k, v in model.named_parameters() if "_dp_module" not in k}
+    return losses, tabs, dense
+
+
+def _e2e_worker(rank, W, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=W)
+    try:
+        _stage_a2a_through_host()
+        from torchrec_amd.distributed.types import ShardingEnv
+
+        keys, model, opt = _e2e_model(ShardingEnv.from_process_group(dist.group.WORLD), dev, dp_max_rows=10)
+        _e2e_init_tables(model)
+        ret[rank] = _e2e_run(model, opt, keys, _e2e_batches(W), rank, W, dev)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dlrm_train_world2_on_one_gpu_matches_world1():
+    W = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_e2e_worker, args=(W, _free_port(), ret), nprocs=W, join=True)
+    from torchrec_amd.distributed.types import ShardingEnv
+
+    dev = torch.device("cuda", 0)
+    keys, model, opt = _e2e_model(ShardingEnv.from_local(1, 0), dev, dp_max_rows=0)
+    _e2e_init_tables(model)
+    losses1, tabs1, dense1 = _e2e_run(model, opt, keys, _e2e_batches(W), 0, 1, dev)
+    l0, t0, d0 = ret[0]
+    l1, t1, d1 = ret[1]
+    # mean loss over the global batch = mean of the two ranks' local means
+    np.testing.assert_allclose((np.array(l0) + np.array(l1)) / 2, np.array(losses1), rtol=2e-4, atol=2e-5)
+    for k in d0:
+        np.testing.assert_array_equal(d0[k], d1[k])  # DDP keeps the replicas identical
+        np.testing.assert_allclose(d0[k], dense1[k], rtol=2e-3, atol=2e-5)
+    seen = {n: 0 for n in tabs1}
+    for tabs in (t0, t1):
+        for n, (w, r0) in tabs.items():
+            np.testing.assert_allclose(w, tabs1[n][0][r0:r0 + w.shape[0]], rtol=2e-3, atol=2e-5)
+            seen[n] += w.shape[0]
+    for n in tabs1:
+        t = int(n[1:])
+        assert seen[n] in (E_ROWS[t], 2 * E_ROWS[t])

@@ -27,6 +27,7 @@ Forward issues the lookup and the a2a before the caller's dense work and waits a
 (`forward()` returns an awaitable), so the exchange overlaps the bottom MLP; autograd replays
 the same overlap in reverse for the gradient exchange.
 """
+import os
 from typing import Any, Callable, Dict, Iterator, List, Optional, Tuple
 
 import torch
@@ -41,6 +42,9 @@ from .planner import rw_block_size, rw_shard_rows
 from .types import Awaitable, LazyAwaitable, NoWait, ParameterSharding, ShardingEnv, ShardingType
 
 GRADIENT_DIVISION = True  # torchrec/distributed/comm_ops.py:35-40
+# Rehearsal switch: run the id / pooled all-to-all and the exchange kernels even at world_size 1
+# (a one-rank RCCL group), so the N > 1 data path can be exercised on a one-GPU box.
+FORCE_EXCHANGE = os.environ.get("TORCHREC_AMD_FORCE_EXCHANGE", "0") == "1"
 
 
 def set_gradient_division(val: bool) -> None:
@@ -217,6 +221,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
         self._pg = env.process_group
         W, me = env.world_size, env.rank
         self._world_size, self._rank = W, me
+        self._exchange = W > 1 or (FORCE_EXCHANGE and self._pg is not None)
         self._device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self._is_weighted = module.is_weighted
         cfgs = module.embedding_bag_configs
@@ -309,7 +314,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
             self._emb_module = factory(
                 [(max(lt.local_rows, 0), lt.cfg.embedding_dim) for lt in self._local_tables],
                 ftm_local * W, pooling_type_to_pooling_mode(cfgs[0].pooling), dev, fused_params)
-            if W > 1:
+            if self._exchange:
                 self._emb_module.set_a2a_output_layout(W)
             self._init_parameters()
             self._optim = EmbeddingFusedOptimizer(self._emb_module, [lt.cfg.name for lt in self._local_tables])
@@ -449,7 +454,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
             send_w = weights.view(nkeys, B * L).index_select(0, order_t) if weights is not None else None
             in_splits = [n * B * L for n in self._send_feats_per_rank]
             out_splits = [self._F_local * B * L] * W
-            if W > 1:
+            if self._exchange:
                 recv_v = torch.empty(sum(out_splits), dtype=send_v.dtype, device=send_v.device)
                 wk = dist.all_to_all_single(recv_v, send_v.view(-1), out_splits, in_splits, group=self._pg, async_op=True)
                 recv_w, wk2 = None, None
@@ -487,7 +492,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
         for n in n_per_rank:
             val_in.append(sum(lpk[k:k + n]))
             k += n
-        if W > 1:
+        if self._exchange:
             recv_l = torch.empty(sum(len_out), dtype=lengths.dtype, device=lengths.device)
             dist.all_to_all_single(recv_l, lengths, len_out, len_in, group=self._pg)
             val_out = recv_l.view(W, -1).sum(dim=1).cpu().tolist()  # host sync (dist_data.py:396-398)
@@ -527,7 +532,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
     def compute_and_output_dist(self, dist_input: SparseFeaturesDist) -> Awaitable[KeyedTensor]:
         B = dist_input.batch_size
         keys, lpe = self._feature_names, self._lengths_per_embedding
-        if self._world_size == 1:
+        if not self._exchange:
             if self._dp_module is None:
                 emb = self._emb_module(dist_input.values, dist_input.offsets, dist_input.weights)
                 return NoWait(KeyedTensor(keys, lpe, emb))
