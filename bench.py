@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--num-batches", type=int, default=16, help="distinct pre-generated batches")
+    ap.add_argument("--hip-graphs", choices=["auto", "on", "off"], default="auto",
+                    help="replay the collective-free dense segments from HIP graphs (auto: N = 1 and batch <= 16384, "
+                         "where host launches show; never under DDP)")
     return ap.parse_args()
 
 
@@ -119,7 +122,8 @@ def main():
                             manual_seed=1234 + rank, num_generated_batches=args.num_batches, device=dev,
                             zipf_alpha=args.zipf or None)
     it = iter(data)
-    pipe = TrainPipelineSparseDist(model, optimizer, dev)
+    hip_graphs = world == 1 and (args.hip_graphs == "on" or (args.hip_graphs == "auto" and B_local <= 16384))
+    pipe = TrainPipelineSparseDist(model, optimizer, dev, hip_graphs=hip_graphs)
     model.train()
     lib = _lib.load()
 
@@ -218,7 +222,7 @@ def main():
             # the reference's only published number is 5 497 159.68 samples/s on 8 x A100-40GB
             # (examples/dlrm/README.MD:45, real Criteo data, end to end) — comparable at N = 8 only
             "vs_baseline": round(value / 5497159.68, 3) if world == 8 else None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic", "hip_graphs": hip_graphs,
             "config": {"workload": "DLRM Criteo-1TB shape: 26 tables (177.9M rows, 84.85 GiB fp32, D=128), 13 dense, "
                                    "pooling factor 1, dense 512-256-128, over 1024-1024-512-256-1, fused exact SGD",
                        "global_batch": args.global_batch, "local_batch": B_local,

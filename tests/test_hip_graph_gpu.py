@@ -1,0 +1,59 @@
+"""HIP-graph replay of the dense segments (distributed/hip_graph.py, DLRMTrain.capture_hip_graphs):
+a graphed train loop must give the eager loop's losses and parameters."""
+import numpy as np
+import pytest
+import torch
+
+import _paths  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def _train(hip_graphs: bool, steps: int = 6):
+    from torchrec_amd.datasets.random import RandomRecDataset
+    from torchrec_amd.distributed.embeddingbag import EmbeddingBagCollectionSharder
+    from torchrec_amd.distributed.model_parallel import DistributedModelParallel
+    from torchrec_amd.distributed.train_pipeline import TrainPipelineSparseDist
+    from torchrec_amd.distributed.types import ShardingEnv
+    from torchrec_amd.models.dlrm import DLRMTrain
+    from torchrec_amd.modules.embedding_configs import EmbeddingBagConfig
+    from torchrec_amd.modules.embedding_modules import EmbeddingBagCollection
+    from torchrec_amd.optim.keyed import CombinedOptimizer, KeyedOptimizerWrapper
+
+    torch.manual_seed(0)
+    dev = torch.device("cuda", 0)
+    rows, D, B, lr = [1000, 3, 57, 20000, 11], 128, 2048, 0.05
+    keys = [f"cat_{i}" for i in range(len(rows))]
+    tables = [EmbeddingBagConfig(name=f"t_{k}", embedding_dim=D, num_embeddings=rows[i], feature_names=[k])
+              for i, k in enumerate(keys)]
+    ebc = EmbeddingBagCollection(tables, device=torch.device("meta"))
+    tm = DLRMTrain(ebc, 13, [512, 256, D], [1024, 512, 1], dense_device=dev)
+    model = DistributedModelParallel(tm, env=ShardingEnv.from_local(1, 0), device=dev,
+                                     sharders=[EmbeddingBagCollectionSharder({"learning_rate": lr})])
+    opt = CombinedOptimizer([model.fused_optimizer,
+                             KeyedOptimizerWrapper(dict(model.named_parameters()), lambda p: torch.optim.SGD(p, lr=lr))])
+    data = RandomRecDataset(keys, B, rows, manual_seed=5, num_generated_batches=4, num_batches=steps + 2, device=dev)
+    pipe = TrainPipelineSparseDist(model, opt, dev, hip_graphs=hip_graphs)
+    model.train()
+    it = iter(data)
+    losses = [float(pipe.progress(it)[0].detach()) for _ in range(steps)]
+    torch.cuda.synchronize()
+    assert (model.module._graphs is not None) == hip_graphs
+    params = {k: v.detach().cpu().numpy().copy() for k, v in model.named_parameters()}
+    shards = {n: w.detach().cpu().numpy().copy() for n, (w, _) in model.sharded_modules()[0].local_shards().items()}
+    return losses, params, shards, model, pipe, data
+
+
+def test_graphed_train_loop_matches_eager():
+    l0, p0, s0, *_ = _train(False)
+    l1, p1, s1, model, pipe, data = _train(True)
+    np.testing.assert_allclose(l1, l0, rtol=1e-5, atol=1e-6)
+    for k in p0:
+        np.testing.assert_allclose(p1[k], p0[k], rtol=1e-4, atol=1e-6, err_msg=k)
+    for k in s0:
+        np.testing.assert_allclose(s1[k], s0[k], rtol=1e-4, atol=1e-6, err_msg=k)
+    # eval / no_grad steps fall back to the eager path and leave the graphs intact
+    model.eval()
+    with torch.no_grad():
+        loss, _ = model(next(iter(data)))
+    assert np.isfinite(float(loss))

@@ -260,7 +260,7 @@ def _e2e_init_tables(model):
             w.copy_(torch.from_numpy(np.random.default_rng(900 + t).standard_normal((E_ROWS[t], D)).astype(np.float32) * 0.1))
 
 
-def _e2e_run(model, opt, keys, batches, rank, W, dev):
+def _e2e_run(model, opt, keys, batches, rank, W, dev, hip_graphs=False):
     from torchrec_amd.datasets.random import Batch
     from torchrec_amd.distributed.train_pipeline import TrainPipelineSparseDist
     from torchrec_amd.sparse.jagged_tensor import KeyedJaggedTensor
@@ -270,13 +270,13 @@ def _e2e_run(model, opt, keys, batches, rank, W, dev):
                 KeyedJaggedTensor.from_fixed_lengths(keys, torch.from_numpy(np.ascontiguousarray(i[:, sl]).reshape(-1)).to(dev),
                                                      [1] * len(keys)),
                 torch.from_numpy(lab[sl]).to(dev)) for d, i, lab in batches]
-    pipe = TrainPipelineSparseDist(model, opt, dev)
+    pipe = TrainPipelineSparseDist(model, opt, dev, hip_graphs=hip_graphs)
     model.train()
     it = iter(bl)
     losses = []
     for _ in range(E_STEPS):
         loss, _ = pipe.progress(it)
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     torch.cuda.synchronize()
     s = model.sharded_modules()[0]
     tabs = {n: (w.detach().cpu().numpy().copy(), r0) for n, (w, r0) in s.local_shards().items()}
@@ -286,7 +286,7 @@ def _e2e_run(model, opt, keys, batches, rank, W, dev):
     return losses, tabs, dense
 
 
-def _e2e_worker(rank, W, port, ret):
+def _e2e_worker(rank, W, port, ret, hip_graphs=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
@@ -298,15 +298,18 @@ def _e2e_worker(rank, W, port, ret):
 
         keys, model, opt = _e2e_model(ShardingEnv.from_process_group(dist.group.WORLD), dev, dp_max_rows=10)
         _e2e_init_tables(model)
-        ret[rank] = _e2e_run(model, opt, keys, _e2e_batches(W), rank, W, dev)
+        ret[rank] = _e2e_run(model, opt, keys, _e2e_batches(W), rank, W, dev, hip_graphs)
     finally:
         dist.destroy_process_group()
 
 
-def test_dlrm_train_world2_on_one_gpu_matches_world1():
+@pytest.mark.parametrize("hip_graphs", [False, True])
+def test_dlrm_train_world2_on_one_gpu_matches_world1(hip_graphs):
+    """hip_graphs=True is declined under DistributedDataParallel (train_pipeline.py): the loop must run
+    eagerly and give the same result."""
     W = 2
     ret = mp.Manager().dict()
-    mp.spawn(_e2e_worker, args=(W, _free_port(), ret), nprocs=W, join=True)
+    mp.spawn(_e2e_worker, args=(W, _free_port(), ret, hip_graphs), nprocs=W, join=True)
     from torchrec_amd.distributed.types import ShardingEnv
 
     dev = torch.device("cuda", 0)

@@ -1,0 +1,123 @@
+"""Forward + backward of a dense sub-module as two HIP graphs.
+
+Why: at the per-rank batch of the 8-GPU configuration (8 192 samples) the DLRM step is bound by
+host launch overhead, not by the GPU: the bottom MLP, the dot interaction, the top MLP and the loss
+are ~70 small launches per direction.  Those segments have static shapes and contain no collective,
+so each is captured once (hipStreamBeginCapture through torch.cuda.graph) and replayed with one
+launch per direction.  The embedding lookup, the all-to-alls and the gradient all-reduce stay
+outside the graphs; autograd sees one Function per segment, so DistributedDataParallel's gradient
+hooks keep firing on the segment's parameters exactly as before.
+
+The reference has no counterpart (it launches every op eagerly through
+torchrec/distributed/train_pipeline.py:520-552); this is the MI355X-side replacement for a
+tracing compiler: explicit capture of the launch-bound inner segments.
+
+Static memory: a segment reads its inputs from, and writes its outputs / input gradients to, fixed
+buffers.  A producer may write straight into `static_input(i)`; when the tensor handed to the
+segment already IS the static buffer no copy is made.  Outputs are overwritten by the next replay
+(the train loop consumes them within the step).  Parameter gradients are handed to autograd as
+views of static buffers, so `zero_grad(set_to_none=True)` (the default of this package's
+optimizers) is required.
+"""
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+from torch import nn
+
+
+class _Replay(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, seg, *flat):
+        for i in range(seg.n_inputs):
+            s, x = seg.static_inputs[i], flat[i]
+            if x.data_ptr() != s.data_ptr():
+                s.copy_(x)
+        seg.fwd_graph.replay()
+        ctx.seg = seg
+        ctx.set_materialize_grads(False)  # an unused output (e.g. logits) costs no zero-fill + copy
+        outs = tuple(o.detach() for o in seg.static_outputs)
+        ctx.mark_non_differentiable(*[o for o, s in zip(outs, seg.static_outputs) if not s.requires_grad])
+        return outs
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *grads):
+        seg = ctx.seg
+        for g, s in zip(grads, seg.static_grad_outputs):
+            if s is not None and g is not None and g.data_ptr() != s.data_ptr():
+                s.copy_(g)
+        seg.bwd_graph.replay()
+        return (None,) + tuple(g.detach() if g is not None else None for g in seg.static_grad_inputs)
+
+
+class GraphedSegment(nn.Module):
+    """`module(*inputs)` with static shapes, replayed from HIP graphs (training mode only)."""
+
+    def __init__(self, module: nn.Module, sample_inputs: Sequence[torch.Tensor],
+                 input_buffers: Optional[Sequence[Optional[torch.Tensor]]] = None, warmup: int = 3,
+                 pool=None) -> None:
+        super().__init__()
+        self.module = module
+        self.n_inputs = len(sample_inputs)
+        input_buffers = list(input_buffers) if input_buffers is not None else [None] * self.n_inputs
+        self.static_inputs: List[torch.Tensor] = []
+        for x, buf in zip(sample_inputs, input_buffers):
+            s = buf if buf is not None else x.detach().clone()
+            s = s.detach().requires_grad_(x.requires_grad)
+            self.static_inputs.append(s)
+        self._params: Tuple[nn.Parameter, ...] = tuple(p for p in module.parameters() if p.requires_grad)
+        self._pool = pool if pool is not None else torch.cuda.graph_pool_handle()
+        self.fwd_graph = torch.cuda.CUDAGraph()
+        self.bwd_graph: Optional[torch.cuda.CUDAGraph] = None
+        self.static_grad_outputs: List[Optional[torch.Tensor]] = []
+        self.static_grad_inputs: List[Optional[torch.Tensor]] = []
+        dev = self.static_inputs[0].device
+        self._stream = torch.cuda.Stream(dev)
+        # ---- warm-up (lazy workspaces, GEMM heuristics) on the capture stream ---------------------
+        torch.cuda.synchronize(dev)
+        with torch.cuda.stream(self._stream):
+            for _ in range(warmup):
+                outs = self._call()
+                need = [o for o in outs if o.requires_grad]
+                if need:
+                    torch.autograd.grad(need, self._grad_targets(), [torch.ones_like(o) for o in need], allow_unused=True)
+            del outs, need
+        self._stream.synchronize()
+        with torch.cuda.graph(self.fwd_graph, pool=self._pool, stream=self._stream, capture_error_mode="thread_local"):
+            self.static_outputs = self._call()
+        self._pool_handle = self._pool
+
+    def _call(self) -> Tuple[torch.Tensor, ...]:
+        out = self.module(*self.static_inputs)
+        return tuple(out) if isinstance(out, (tuple, list)) else (out,)
+
+    def _grad_targets(self) -> List[torch.Tensor]:
+        return [x for x in self.static_inputs if x.requires_grad] + list(self._params)
+
+    def static_input(self, i: int) -> torch.Tensor:
+        return self.static_inputs[i]
+
+    def capture_backward(self, grad_output_buffers: Optional[Sequence[Optional[torch.Tensor]]] = None) -> None:
+        """Captures d(outputs)/d(inputs, parameters).  `grad_output_buffers[i]` lets a downstream
+        segment's static input-gradient buffer double as this segment's output-gradient buffer."""
+        outs = self.static_outputs
+        bufs = list(grad_output_buffers) if grad_output_buffers is not None else [None] * len(outs)
+        self.static_grad_outputs = [
+            (bufs[i] if bufs[i] is not None else torch.zeros_like(o)) if o.requires_grad else None
+            for i, o in enumerate(outs)]
+        need = [o for o in outs if o.requires_grad]
+        targets = self._grad_targets()
+        self.bwd_graph = torch.cuda.CUDAGraph()
+        self._stream.synchronize()
+        with torch.cuda.graph(self.bwd_graph, pool=self._pool, stream=self._stream, capture_error_mode="thread_local"):
+            grads = torch.autograd.grad(need, targets, [g for g in self.static_grad_outputs if g is not None],
+                                        allow_unused=True)
+        it = iter(grads)
+        self.static_grad_inputs = [next(it) if x.requires_grad else None for x in self.static_inputs]
+        self.static_grad_inputs += list(it)  # parameter gradients, in self._params order
+
+    def forward(self, *inputs: torch.Tensor):
+        if self.bwd_graph is None:
+            raise RuntimeError("GraphedSegment.capture_backward() has not run")
+        outs = _Replay.apply(self, *inputs, *self._params)
+        return outs if len(outs) > 1 else outs[0]

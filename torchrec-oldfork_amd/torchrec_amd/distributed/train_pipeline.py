@@ -37,8 +37,16 @@ class _PipelinedEBC(torch.nn.Module):
 
 
 class TrainPipelineSparseDist:
-    def __init__(self, model: torch.nn.Module, optimizer: Any, device: torch.device) -> None:
+    def __init__(self, model: torch.nn.Module, optimizer: Any, device: torch.device, hip_graphs: bool = False) -> None:
         self._model, self._optimizer, self._device = model, optimizer, device
+        # hip_graphs: capture the model's collective-free dense segments as HIP graphs on the first
+        # batch (models that offer `capture_hip_graphs(batch_size)`, distributed/hip_graph.py)
+        # Declined under DistributedDataParallel (world_size > 1): replaying the segments' backward under
+        # DDP's bucket-view gradient hooks crashed in the 2-rank rehearsal (tests/test_multirank_gpu.py),
+        # and the measured gain at the 8-GPU per-rank batch is only ~4 % (the step is GEMM-bound there).
+        self._hip_graphs = hip_graphs and device.type == "cuda"
+        if isinstance(model, DistributedModelParallel) and model._env.world_size > 1:
+            self._hip_graphs = False
         use_streams = device.type == "cuda"
         self._memcpy_stream = torch.cuda.Stream(device) if use_streams else None
         self._data_dist_stream = torch.cuda.Stream(device) if use_streams else None
@@ -80,6 +88,11 @@ class TrainPipelineSparseDist:
         with torch.cuda.stream(self._memcpy_stream):
             self._batch_i = self._to_device(next(it), True)
             self._batch_ip1 = self._to_device(next(it, None), True)
+        if self._hip_graphs:
+            root = self._model.module if isinstance(self._model, DistributedModelParallel) else self._model
+            if hasattr(root, "capture_hip_graphs"):
+                self._memcpy_stream.synchronize()
+                root.capture_hip_graphs(int(self._batch_i.dense_features.shape[0]))  # before any collective is in flight
         with torch.cuda.stream(self._data_dist_stream):
             self._data_dist_stream.wait_stream(self._memcpy_stream)
             self._start_data_dist(self._batch_i)

@@ -160,6 +160,19 @@ class DLRM(nn.Module):
         return self.over_arch(concatenated)
 
 
+class _Head(nn.Module):
+    """interaction + over arch + loss as ONE static-shape segment (inputs: bottom-MLP output, pooled
+    embeddings [B, F, D], labels as float) -> (loss, logits)."""
+
+    def __init__(self, inter_arch: nn.Module, over_arch: nn.Module, loss_fn: nn.Module) -> None:
+        super().__init__()
+        self.inter_arch, self.over_arch, self.loss_fn = inter_arch, over_arch, loss_fn
+
+    def forward(self, embedded_dense: torch.Tensor, embedded_sparse: torch.Tensor, labels: torch.Tensor):
+        logits = self.over_arch(self.inter_arch(dense_features=embedded_dense, sparse_features=embedded_sparse)).squeeze(-1)
+        return self.loss_fn(logits, labels), logits
+
+
 class DLRMTrain(nn.Module):
     """examples/dlrm/modules/dlrm_train.py: BCEWithLogits wrapper used by the train pipeline."""
 
@@ -170,8 +183,41 @@ class DLRMTrain(nn.Module):
         self.model = DLRM(embedding_bag_collection, dense_in_features, dense_arch_layer_sizes,
                           over_arch_layer_sizes, dense_device)
         self.loss_fn = nn.BCEWithLogitsLoss()
+        self._graphs = None  # (batch size, bottom-MLP segment, head segment)
+
+    def capture_hip_graphs(self, batch_size: int) -> None:
+        """Captures the two collective-free dense segments of a train step — bottom MLP; interaction
+        + top MLP + loss — as HIP graphs for this per-rank batch size (distributed/hip_graph.py).
+        Steps with another batch size, eval mode or no_grad run eagerly as before."""
+        from ..distributed.hip_graph import GraphedSegment
+
+        m = self.model
+        p = next(m.dense_arch.parameters())
+        dev, B = p.device, batch_size
+        F, D = m.sparse_arch.F, m.sparse_arch.D
+        dense_in = m.dense_arch.model._mlp[0]._in_size
+        g_dense = GraphedSegment(m.dense_arch, [torch.randn(B, dense_in, device=dev)])
+        head = _Head(m.inter_arch, m.over_arch, self.loss_fn)
+        g_head = GraphedSegment(
+            head, [g_dense.static_outputs[0].detach().requires_grad_(True),
+                   torch.randn(B, F, D, device=dev).requires_grad_(True),
+                   torch.randint(0, 2, (B,), device=dev).float()],
+            input_buffers=[g_dense.static_outputs[0], None, None], pool=g_dense._pool)
+        g_head.capture_backward()
+        # the head's gradient w.r.t. the bottom-MLP output doubles as the bottom segment's grad_output buffer
+        g_dense.capture_backward([g_head.static_grad_inputs[0]])
+        object.__setattr__(self, "_graphs", (B, g_dense, g_head))  # not sub-modules: state_dict keys unchanged
 
     def forward(self, batch) -> Tuple[torch.Tensor, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
+        g = self._graphs
+        if (g is not None and self.training and torch.is_grad_enabled()
+                and batch.dense_features.shape[0] == g[0] and batch.dense_features.is_cuda):
+            _, g_dense, g_head = g
+            pending = self.model.sparse_arch.start(batch.sparse_features)
+            embedded_dense = g_dense(batch.dense_features)
+            embedded_sparse = self.model.sparse_arch.finish(pending)
+            loss, logits = g_head(embedded_dense, embedded_sparse, batch.labels.float())
+            return loss, (loss.detach(), logits.detach(), batch.labels.detach())
         logits = self.model(batch.dense_features, batch.sparse_features).squeeze(-1)
         loss = self.loss_fn(logits, batch.labels.float())
         return loss, (loss.detach(), logits.detach(), batch.labels.detach())
