@@ -181,6 +181,54 @@ int tbe_backward_apply_f32(const uint64_t* feat_weights, const int32_t* feat_D,
                            void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * HBM row cache for EmbeddingLocation.MANAGED_CACHING tables (the `batched_fused_uvm_caching`
+ * compute kernel: torchrec/distributed/embedding_types.py:57-76; `flush()` before weights are
+ * read: batched_embedding_kernel.py:563,664; default cache_load_factor 0.2:
+ * planner/constants.py:26).  The tables stay in pinned, GPU-mapped host memory; a 64-way
+ * set-associative cache in HBM holds the rows in use.  The TBE kernels above are unchanged:
+ * tbe_cache_prefetch rewrites the ids of cached features into slot numbers of ONE pseudo-table
+ * [num_sets*64 cache slots | staging_cap staging slots] (`rows`, row stride `row_stride`), and the
+ * caller points the feat_* metadata of those features at it (feat_weights = rows, feat_rows =
+ * num_sets*64 + staging_cap, feat_state0 = state).  Rows that find no evictable way are held in
+ * the staging slots for this batch; tbe_cache_writeback_staging copies them home after backward.
+ * Results are identical to an uncached table.
+ *
+ *   tags [slots] int64  cached-row key (tab_key_base[t] + local row), -1 = empty
+ *   lru  [slots] int32  iteration of last use, -1 = never; `iteration` must increase per prefetch
+ *   rows [(slots + staging_cap) * row_stride] float;  state: same slots, rowwise optimizer state or NULL
+ *   staging_keys [staging_cap] int64;  counters [8] int32: 0 staging rows of this batch, 1 hits,
+ *   2 misses, 3 evictions (write-backs), 4 unique cached rows of this batch, 5 misses of this batch
+ *   tab_* : the cached tables (num_tables entries; tab_key_base has num_tables+1 = prefix sum of rows)
+ * tbe_cache_prefetch: feat_cached_table[f] = index into tab_* or -1 (ids of such features are copied
+ *   unchanged); key_bits = bits of the total cached rows; staging_cap must be >= N.
+ * tbe_cache_flush: every valid slot -> host table; invalidate != 0 also empties the cache.
+ * ---------------------------------------------------------------------------------- */
+typedef struct tbe_cache_desc {
+  int64_t* tags;
+  int32_t* lru;
+  float* rows;
+  float* state;
+  int64_t* staging_keys;
+  int32_t* counters;
+  const int64_t* tab_key_base;
+  const uint64_t* tab_weights;
+  const uint64_t* tab_state;
+  const int32_t* tab_D;
+  int32_t num_sets;
+  int32_t row_stride;
+  int32_t staging_cap;
+  int32_t num_tables;
+} tbe_cache_desc;
+size_t tbe_cache_prefetch_workspace_bytes(int64_t N, int32_t key_bits);
+int tbe_cache_prefetch(const tbe_cache_desc* desc, const int32_t* feat_cached_table,
+                       const int64_t* feat_rows, int32_t F, int32_t B, const int64_t* indices,
+                       int64_t N, const int64_t* offsets, int32_t key_bits, int32_t iteration,
+                       int64_t* remapped_indices, void* workspace, size_t workspace_bytes,
+                       void* stream);
+int tbe_cache_writeback_staging(const tbe_cache_desc* desc, void* stream);
+int tbe_cache_flush(const tbe_cache_desc* desc, int32_t invalidate, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * torch.ops.fbgemm.asynchronous_complete_cumsum (torchrec/sparse/jagged_tensor.py:35-36):
  * out[0] = 0, out[i+1] = sum(in[0..i]); out has n+1 entries.  elem_size 4 (int32) or
  * 8 (int64).  workspace >= tbe_cumsum_workspace_bytes(n).

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_totals_kernel(const KeyT* 
 }
 
 // grid = passes * radix workgroups: workgroup (p, d) sums the kTotalsBlocks partial counts of digit d.
-__global__ __launch_bounds__(kSortThreads) void radix_totals_reduce_kernel(const uint32_t* __restrict__ totals_part,
+static __global__ __launch_bounds__(kSortThreads) void radix_totals_reduce_kernel(const uint32_t* __restrict__ totals_part,
                                                                           int row, uint32_t* __restrict__ totals) {
   __shared__ uint32_t wave_tot[kSortWaves];
   const int pd = blockIdx.x;  // p * radix + d
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_totals_reduce_kernel(const
 }
 
 // grid = radix workgroups (one per digit)
-__global__ __launch_bounds__(kSortThreads) void radix_offsets_kernel(uint32_t* __restrict__ hist,
+static __global__ __launch_bounds__(kSortThreads) void radix_offsets_kernel(uint32_t* __restrict__ hist,
                                                                     const uint32_t* __restrict__ totals, int64_t ntiles) {
   __shared__ uint32_t wave_tot[kSortWaves];
   __shared__ uint32_t digit_base;

@@ -35,6 +35,17 @@ class OptimizerArgs(ctypes.Structure):
     ]
 
 
+class CacheDesc(ctypes.Structure):
+    """Mirror of ``tbe_cache_desc`` (include/tbe_hip.h)."""
+
+    _fields_ = [
+        ("tags", c_void_p), ("lru", c_void_p), ("rows", c_void_p), ("state", c_void_p),
+        ("staging_keys", c_void_p), ("counters", c_void_p), ("tab_key_base", c_void_p),
+        ("tab_weights", c_void_p), ("tab_state", c_void_p), ("tab_D", c_void_p),
+        ("num_sets", c_i32), ("row_stride", c_i32), ("staging_cap", c_i32), ("num_tables", c_i32),
+    ]
+
+
 # name -> (restype, argtypes); must list every symbol of include/tbe_hip.h
 SIGNATURES = {
     "tbe_last_error": (ctypes.c_char_p, []),
@@ -70,6 +81,14 @@ SIGNATURES = {
          c_i32, c_i32, c_void_p, c_i64, c_void_p, c_void_p, c_i32, c_void_p, c_i64, OptimizerArgs,
          c_i32, c_void_p, c_size, c_void_p],
     ),
+    "tbe_cache_prefetch_workspace_bytes": (c_size, [c_i64, c_i32]),
+    "tbe_cache_prefetch": (
+        ctypes.c_int,
+        [ctypes.POINTER(CacheDesc), c_void_p, c_void_p, c_i32, c_i32, c_void_p, c_i64, c_void_p, c_i32, c_i32,
+         c_void_p, c_void_p, c_size, c_void_p],
+    ),
+    "tbe_cache_writeback_staging": (ctypes.c_int, [ctypes.POINTER(CacheDesc), c_void_p]),
+    "tbe_cache_flush": (ctypes.c_int, [ctypes.POINTER(CacheDesc), c_i32, c_void_p]),
     "tbe_cumsum_workspace_bytes": (c_size, [c_i64]),
     "tbe_cumsum": (ctypes.c_int, [c_void_p, c_void_p, c_i64, c_i32, c_i32, c_void_p, c_size, c_void_p]),
     "tbe_permute_2d_workspace_bytes": (c_size, [c_i32, c_i32, c_i32]),

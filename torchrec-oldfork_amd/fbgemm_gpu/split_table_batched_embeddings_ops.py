@@ -12,6 +12,7 @@ There is no CPU implementation here: ``ComputeDevice.CPU`` / ``use_cpu=True`` ra
 import enum
 import os
 import types
+from ctypes import byref as ctypes_byref
 from dataclasses import dataclass
 from typing import List, Optional, Tuple
 
@@ -19,7 +20,7 @@ import torch
 from torch import nn
 
 from . import _lib
-from ._lib import OptimizerArgs, check, ptr, require_gpu, stream_ptr, workspace
+from ._lib import CacheDesc, OptimizerArgs, check, ptr, require_gpu, stream_ptr, workspace
 from .split_embedding_configs import EmbOptimType as OptimType
 from .split_embedding_configs import SparseType
 
@@ -116,6 +117,169 @@ class _Layout:
         self.feat_state1 = None
 
 
+class _RowCache:
+    """HBM row cache of a module's EmbeddingLocation.MANAGED_CACHING tables (csrc/tbe_cache.hip).
+
+    The tables stay in pinned host memory; `rows` = [num_sets * 64 cache slots | staging slots] in HBM.
+    `prefetch` rewrites a batch's ids of cached features into slot numbers, and the module's kernels
+    see those features as lookups into the pseudo-table `rows` (see `redirect`)."""
+
+    WAYS = 64
+
+    def __init__(self, module: "_TBEBase", tables: List[int], load_factor: float, cache_sets: int,
+                 rowwise_state: bool) -> None:
+        self.m = module
+        self.tables = tables
+        dims = {module.dims_per_table[t] for t in tables}
+        if len(dims) != 1:
+            raise NotImplementedError("MANAGED_CACHING tables of one module must share one embedding dim")
+        self.D = dims.pop()
+        rows = [module.rows_per_table[t] for t in tables]
+        self.key_base = [0]
+        for r in rows:
+            self.key_base.append(self.key_base[-1] + r)
+        total = self.key_base[-1]
+        self.key_bits = max(1, int(total).bit_length())
+        if not 0.0 < load_factor <= 1.0:
+            raise ValueError("cache_load_factor must be in (0, 1]")
+        self.num_sets = int(cache_sets) if cache_sets else max(1, -(-int(total * load_factor) // self.WAYS))
+        self.slots = self.num_sets * self.WAYS
+        self.rowwise_state = rowwise_state
+        self.staging_cap = 0
+        self.iteration = 0
+        self.pending = False   # a training forward whose backward has not run yet
+        self.dirty = False     # cached rows may differ from the host tables
+        self.rows: Optional[torch.Tensor] = None
+        self.state: Optional[torch.Tensor] = None
+        dev = module.current_device
+        self.tags = torch.full((self.slots,), -1, dtype=torch.int64, device=dev)
+        self.lru = torch.full((self.slots,), -1, dtype=torch.int32, device=dev)
+        self.counters = torch.zeros(8, dtype=torch.int32, device=dev)
+        self.staging_keys: Optional[torch.Tensor] = None
+        self.tab_key_base = torch.tensor(self.key_base, dtype=torch.int64).to(dev)
+        self.tab_D = torch.tensor([self.D] * len(tables), dtype=torch.int32).to(dev)
+        ctab = {t: i for i, t in enumerate(tables)}
+        self.feat_ctab_host = [ctab.get(t, -1) for t in module.feature_table_map]
+        self.feat_ctab = torch.tensor(self.feat_ctab_host, dtype=torch.int32).to(dev)
+        self.cached_feats = torch.tensor([f for f, c in enumerate(self.feat_ctab_host) if c >= 0], dtype=torch.int64).to(dev)
+        self._desc_key = None
+        self._desc = None
+        self._tab_ptrs = None
+        self._redirect_key = None
+        self._redirected = None
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        for k in ("_desc", "_desc_key", "_tab_ptrs", "_redirect_key", "_redirected"):
+            d[k] = None  # ctypes descriptors / device pointer tables are rebuilt on demand
+        return d
+
+    # -- storage ----------------------------------------------------------------------------
+    def ensure(self, N: int) -> None:
+        """(Re)allocates rows / state so that the staging area holds a batch of N ids."""
+        if self.rows is not None and N <= self.staging_cap:
+            return
+        if self.pending:
+            raise RuntimeError("MANAGED_CACHING: the staging area cannot grow between a training forward and its backward")
+        dev = self.m.current_device
+        cap = max(1024, -(-max(N, 2 * self.staging_cap) // 1024) * 1024)
+        rows = torch.zeros((self.slots + cap) * self.D, dtype=torch.float32, device=dev)
+        state = torch.zeros(self.slots + cap, dtype=torch.float32, device=dev) if self.rowwise_state else None
+        if self.rows is not None:  # keep the cached rows (tags / lru stay valid)
+            rows[:self.slots * self.D].copy_(self.rows[:self.slots * self.D])
+            if state is not None:
+                state[:self.slots].copy_(self.state[:self.slots])
+        self.rows, self.state, self.staging_cap = rows, state, cap
+        self.staging_keys = torch.zeros(cap, dtype=torch.int64, device=dev)
+        self.m.key_bits = _bit_length(self.m.total_rows + self.slots + cap)
+
+    def desc(self) -> CacheDesc:
+        m = self.m
+        m._ensure_pinned()
+        wbase = m._flat_weights("uvm").data_ptr()
+        sbase = m._state_flat("momentum1", "uvm").data_ptr() if self.rowwise_state else 0
+        key = (wbase, sbase, self.rows.data_ptr(), self.staging_cap)
+        if self._desc_key != key:
+            dev = m.current_device
+            w = torch.tensor([wbase + 4 * m.weights_offsets[t] for t in self.tables], dtype=torch.int64).to(dev)
+            st = (torch.tensor([sbase + 4 * m.state_row_offsets[t] for t in self.tables], dtype=torch.int64).to(dev)
+                  if self.rowwise_state else None)
+            self._tab_ptrs = (w, st)
+            self._desc = CacheDesc(ptr(self.tags), ptr(self.lru), ptr(self.rows), ptr(self.state), ptr(self.staging_keys),
+                                   ptr(self.counters), ptr(self.tab_key_base), ptr(w), ptr(st), ptr(self.tab_D),
+                                   self.num_sets, self.D, self.staging_cap, len(self.tables))
+            self._desc_key = key
+        return self._desc
+
+    def redirect(self, lay: "_Layout") -> "_Layout":
+        """The module's feature metadata with the cached features pointing at the pseudo-table."""
+        key = (lay.key, self.rows.data_ptr(), self.staging_cap)
+        if self._redirect_key != key:
+            r = _Layout()
+            r.key = key
+            cf = self.cached_feats
+            r.feat_weights = lay.feat_weights.clone()
+            r.feat_weights[cf] = self.rows.data_ptr()
+            r.feat_rows = lay.feat_rows.clone()
+            r.feat_rows[cf] = self.slots + self.staging_cap
+            r.feat_row_base = lay.feat_row_base.clone()
+            r.feat_row_base[cf] = self.m.total_rows
+            r.feat_D, r.feat_out_offset = lay.feat_D, lay.feat_out_offset
+            r.feat_state0, r.feat_state1 = lay.feat_state0, lay.feat_state1
+            if self.rowwise_state:
+                r.feat_state0 = lay.feat_state0.clone()
+                r.feat_state0[cf] = self.state.data_ptr()
+            self._redirected, self._redirect_key = r, key
+        return self._redirected
+
+    # -- per-step ---------------------------------------------------------------------------
+    def prefetch(self, real: "_Layout", indices: torch.Tensor, offsets: torch.Tensor, B: int, training: bool) -> torch.Tensor:
+        if self.pending:
+            raise RuntimeError("MANAGED_CACHING supports one outstanding training forward per module: run the "
+                               "backward of the previous forward first")
+        N = indices.numel()
+        self.ensure(N)
+        dev = self.m.current_device
+        lib = _lib.load()
+        out = torch.empty_like(indices)
+        self.iteration += 1
+        if self.iteration >= (1 << 25):
+            raise RuntimeError("MANAGED_CACHING: iteration counter exhausted; flush() and rebuild the module's cache")
+        with torch.cuda.device(dev):
+            ws = workspace(lib.tbe_cache_prefetch_workspace_bytes(N, self.key_bits), dev)
+            check(lib.tbe_cache_prefetch(ctypes_byref(self.desc()), ptr(self.feat_ctab), ptr(real.feat_rows), self.m.F, B,
+                                         ptr(indices), N, ptr(offsets), self.key_bits, self.iteration, ptr(out), ptr(ws),
+                                         ws.numel(), stream_ptr(dev)),
+                  "tbe_cache_prefetch")
+        self.pending = training
+        self.dirty = self.dirty or training
+        return out
+
+    def after_backward(self) -> None:
+        dev = self.m.current_device
+        with torch.cuda.device(dev):
+            check(_lib.load().tbe_cache_writeback_staging(ctypes_byref(self.desc()), stream_ptr(dev)),
+                  "tbe_cache_writeback_staging")
+        self.pending = False
+
+    def flush(self, invalidate: bool) -> None:
+        if self.rows is None or (not self.dirty and not invalidate):
+            return
+        if self.pending:
+            raise RuntimeError("MANAGED_CACHING: flush() between a training forward and its backward")
+        dev = self.m.current_device
+        with torch.cuda.device(dev):
+            check(_lib.load().tbe_cache_flush(ctypes_byref(self.desc()), 1 if invalidate else 0, stream_ptr(dev)),
+                  "tbe_cache_flush")
+        torch.cuda.current_stream(dev).synchronize()  # host views are read / written by the caller next
+        self.dirty = False
+
+    def stats(self) -> dict:
+        c = self.counters.cpu().tolist()
+        return {"hits": c[1], "misses": c[2], "evictions": c[3], "unique_last_batch": c[4], "misses_last_batch": c[5],
+                "staged_last_batch": c[0], "num_sets": self.num_sets, "slots": self.slots}
+
+
 class _TBEBase(nn.Module):
     """Storage + launch logic shared by the fused (split) and dense variants."""
 
@@ -185,6 +349,7 @@ class _TBEBase(nn.Module):
         self._flat_sizes = sizes
         self._row_sizes = row_sizes
         self._layout = _Layout()
+        self._cache: Optional[_RowCache] = None
         self._bounds_errors: Optional[torch.Tensor] = None
         self._side_stream = None
         # sort the batch's row keys on a side stream during forward (see _prepare_backward)
@@ -192,6 +357,15 @@ class _TBEBase(nn.Module):
         # side-stream sort steals bandwidth from the GEMMs, -2 %; at 213 K ids it hides, +4 %)
         self.overlap_backward_sort = os.environ.get("TBE_OVERLAP_SORT", "auto")
         self.overlap_backward_sort_max_ids = 1 << 20
+
+    def __getstate__(self):
+        # copy.deepcopy / pickling (model_parallel.py:294-298 deep-copies sharded modules): HIP streams
+        # cannot be copied and device-pointer tables must be rebuilt for the copy's own storage
+        d = self.__dict__.copy()
+        d["_side_stream"] = None
+        d["_layout"] = _Layout()
+        d["_pinned_key"] = None
+        return d
 
     # -- storage helpers ------------------------------------------------------------------
     def _alloc(self, placement: str, numel: int) -> torch.Tensor:
@@ -213,7 +387,11 @@ class _TBEBase(nn.Module):
 
     def split_embedding_weights(self) -> List[torch.Tensor]:
         """Per-table ``[rows, dim]`` views aliasing the module's storage
-        (written in place by batched_embedding_kernel.py:541-544 and embedding_lookup.py:70)."""
+        (written in place by batched_embedding_kernel.py:541-544 and embedding_lookup.py:70).
+        With MANAGED_CACHING tables the HBM row cache is written back and emptied first, so the views
+        are current and the caller may write them."""
+        if self._cache is not None:
+            self._cache.flush(invalidate=True)
         return [self._table_view(self._flat_weights, t) for t in range(self.T)]
 
     # -- device metadata --------------------------------------------------------------------
@@ -224,6 +402,26 @@ class _TBEBase(nn.Module):
         return (self._flat_weights("dev").data_ptr(), self._flat_weights("uvm").data_ptr())
 
     def _get_layout(self) -> _Layout:
+        lay = self._real_layout()
+        if self._cache is not None and self._cache.rows is not None:
+            return self._cache.redirect(lay)
+        return lay
+
+    def _ensure_pinned(self) -> None:
+        """Host-resident (MANAGED*) buffers must be pinned to be addressable by the kernels; a
+        copy.deepcopy of the module (model_parallel.py:294-298) yields pageable copies — re-pin them."""
+        names = [n for n, b in self._buffers.items() if n.endswith("_uvm") and b is not None and b.numel() > 0
+                 and b.device.type == "cpu"]
+        key = tuple(self._buffers[n].data_ptr() for n in names)
+        if key == getattr(self, "_pinned_key", None):
+            return
+        for n in names:
+            if not self._buffers[n].is_pinned():
+                self._buffers[n] = self._buffers[n].pin_memory()
+        self._pinned_key = tuple(self._buffers[n].data_ptr() for n in names)
+
+    def _real_layout(self) -> _Layout:
+        self._ensure_pinned()
         s0, s1 = self._state_ptrs()
         key = (self._storage_key(), tuple(s0 or ()), tuple(s1 or ()))
         lay = self._layout
@@ -448,6 +646,8 @@ class _FusedLookupInto(torch.autograd.Function):
         module._backward_impl(grad_out, indices, offsets, psw, ctx.B, module._optimizer_struct(),
                               prepared=ctx.prepared, layout=ctx.layout)
         ctx.prepared = None
+        if module._cache is not None:
+            module._cache.after_backward()
         return (grad_out,) + (None,) * 9
 
 
@@ -493,6 +693,8 @@ class _FusedLookup(torch.autograd.Function):
         module._backward_impl(grad_out, indices, offsets, psw, ctx.B, module._optimizer_struct(),
                               prepared=ctx.prepared)
         ctx.prepared = None
+        if module._cache is not None:
+            module._cache.after_backward()
         return None, None, None, None, None, None, None
 
 
@@ -575,6 +777,11 @@ class SplitTableBatchedEmbeddingBagsCodegen(_TBEBase):
                 if needed:
                     n = self._row_sizes[p] if rowwise else self._flat_sizes[p]
                 self.register_buffer(f"{name}_{p}", self._alloc(p, n), persistent=False)
+        # HBM row cache for the MANAGED_CACHING tables (SGD / row-wise Adagrad; tables whose optimizer
+        # keeps per-element state are served straight from host memory, like MANAGED)
+        cached = [t for t, loc in enumerate(self.locations) if loc == EmbeddingLocation.MANAGED_CACHING]
+        if cached and code in (0, 1) and self.current_device.type == "cuda":
+            self._cache = _RowCache(self, cached, cache_load_factor, cache_sets, rowwise_state=rowwise)
         # A zero-size leaf that requires grad so autograd reaches backward.  Deliberately NOT an
         # nn.Parameter: it must stay invisible to DistributedDataParallel and to dense optimizers
         # (the reference hides its counterpart with `named_parameters -> ()`,
@@ -611,6 +818,8 @@ class SplitTableBatchedEmbeddingBagsCodegen(_TBEBase):
         """Per-table optimizer state views (batched_embedding_kernel.py:133-148):
         ``()`` for SGD, ``(momentum1[rows],)`` for row-wise Adagrad,
         ``(m[rows, D], v[rows, D])`` for Adam, ``(momentum1[rows, D],)`` for Adagrad."""
+        if self._cache is not None:
+            self._cache.flush(invalidate=True)
         code = _OPT_CODE[self.optimizer]
         states: List[Tuple[torch.Tensor, ...]] = []
         for t in range(self.T):
@@ -635,9 +844,14 @@ class SplitTableBatchedEmbeddingBagsCodegen(_TBEBase):
         self.optimizer_args.learning_rate = float(lr)
 
     def flush(self) -> None:
-        """Write-back hook for MANAGED_CACHING (batched_embedding_kernel.py:563, 664).
-        Tables are read and updated in place (no HBM row cache yet), so nothing is pending."""
-        return None
+        """Write-back of the HBM row cache of MANAGED_CACHING tables to their host tables
+        (batched_embedding_kernel.py:563, 664); the cache stays warm."""
+        if self._cache is not None:
+            self._cache.flush(invalidate=False)
+
+    def cache_stats(self) -> Optional[dict]:
+        """Hit / miss / eviction counters of the HBM row cache (None without MANAGED_CACHING tables). Syncs."""
+        return self._cache.stats() if self._cache is not None else None
 
     def _optimizer_struct(self) -> OptimizerArgs:
         a = self.optimizer_args
@@ -648,6 +862,8 @@ class SplitTableBatchedEmbeddingBagsCodegen(_TBEBase):
                 per_sample_weights: Optional[torch.Tensor] = None,
                 feature_requires_grad: Optional[torch.Tensor] = None) -> torch.Tensor:
         indices, offsets, per_sample_weights, B = self._check_inputs(indices, offsets, per_sample_weights)
+        if self._cache is not None:
+            indices = self._cache.prefetch(self._real_layout(), indices, offsets, B, torch.is_grad_enabled())
         mode = self.overlap_backward_sort
         prepare = torch.is_grad_enabled() and (
             mode in (True, "1") or (mode == "auto" and indices.numel() <= self.overlap_backward_sort_max_ids))
@@ -659,6 +875,8 @@ class SplitTableBatchedEmbeddingBagsCodegen(_TBEBase):
         """Pooled lookup whose feature blocks land at `out[b * row_stride + out_offsets[f] + d]` of the
         given buffer (returned, marked dirty for autograd)."""
         indices, offsets, per_sample_weights, B = self._check_inputs(indices, offsets, per_sample_weights)
+        if self._cache is not None:
+            indices = self._cache.prefetch(self._real_layout(), indices, offsets, B, torch.is_grad_enabled())
         mode = self.overlap_backward_sort
         prepare = torch.is_grad_enabled() and (
             mode in (True, "1") or (mode == "auto" and indices.numel() <= self.overlap_backward_sort_max_ids))
