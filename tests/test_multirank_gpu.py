@@ -65,9 +65,9 @@ def _data(W, fixed_len, weighted, seed=11):
     return per_rank, init
 
 
-def _build_sharded(W, backend_env, weighted, n_rw, dp_max_rows):
+def _build_sharded(W, backend_env, weighted, n_rw, dp_max_rows, offload=False):
     from torchrec_amd.distributed.embeddingbag import ShardedEmbeddingBagCollection
-    from torchrec_amd.distributed.planner import EmbeddingShardingPlanner, Topology
+    from torchrec_amd.distributed.planner import EmbeddingShardingPlanner, ParameterConstraints, Topology
     from torchrec_amd.modules.embedding_configs import EmbeddingBagConfig
     from torchrec_amd.modules.embedding_modules import EmbeddingBagCollection
 
@@ -75,8 +75,14 @@ def _build_sharded(W, backend_env, weighted, n_rw, dp_max_rows):
     tables = [EmbeddingBagConfig(name=f"t{i}", embedding_dim=D, num_embeddings=ROWS[i], feature_names=[keys[i]])
               for i in range(len(ROWS))]
     ebc = EmbeddingBagCollection(tables, is_weighted=weighted, device=torch.device("meta"))
-    plan = EmbeddingShardingPlanner(Topology(W), num_row_wise=n_rw, dp_max_rows=dp_max_rows).plan_tables(tables)
-    sebc = ShardedEmbeddingBagCollection(ebc, plan, backend_env, {"learning_rate": LR}, torch.device("cuda", 0))
+    # offload: the largest table row-wise in host memory behind the HBM row cache (tiny cache: evictions),
+    # another one table-wise in plain host-mapped memory
+    cons = ({"t3": ParameterConstraints(["row_wise"], ["batched_fused_uvm_caching"]),
+             "t0": ParameterConstraints(["table_wise"], ["batched_fused_uvm"])} if offload else None)
+    plan = EmbeddingShardingPlanner(Topology(W), constraints=cons, num_row_wise=n_rw,
+                                    dp_max_rows=dp_max_rows).plan_tables(tables)
+    fused = {"learning_rate": LR, "cache_sets": 2} if offload else {"learning_rate": LR}
+    sebc = ShardedEmbeddingBagCollection(ebc, plan, backend_env, fused, torch.device("cuda", 0))
     return keys, plan, sebc
 
 
@@ -115,7 +121,7 @@ def _run_rank(sebc, keys, per_rank, init, rank, W, fixed_len, weighted):
     return vals_out.detach().cpu().numpy().copy(), shards
 
 
-def _worker(rank, W, port, fixed_len, weighted, n_rw, dp_max_rows, ret):
+def _worker(rank, W, port, fixed_len, weighted, n_rw, dp_max_rows, ret, offload=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
@@ -125,8 +131,11 @@ def _worker(rank, W, port, fixed_len, weighted, n_rw, dp_max_rows, ret):
         from torchrec_amd.distributed.types import ShardingEnv
 
         per_rank, init = _data(W, fixed_len, weighted)
-        keys, plan, sebc = _build_sharded(W, ShardingEnv.from_process_group(dist.group.WORLD), weighted, n_rw, dp_max_rows)
+        keys, plan, sebc = _build_sharded(W, ShardingEnv.from_process_group(dist.group.WORLD), weighted, n_rw, dp_max_rows,
+                                          offload)
         out, shards = _run_rank(sebc, keys, per_rank, init, rank, W, fixed_len, weighted)
+        if offload:
+            assert plan["t3"].compute_kernel == "batched_fused_uvm_caching" and sebc._emb_module._cache is not None
         ret[rank] = (out, shards, {n: p.sharding_type for n, p in plan.items()})
     finally:
         dist.destroy_process_group()
@@ -196,6 +205,15 @@ def _rccl_worker(rank, port, fixed_len, weighted, dp_max_rows, ret):
         ret[0] = (out, shards, {n: p.sharding_type for n, p in plan.items()})
     finally:
         dist.destroy_process_group()
+
+
+def test_sharded_world2_with_host_offloaded_tables():
+    """Row-wise shards of a table in host memory behind the HBM row cache + a table-wise table in plain
+    host-mapped memory (BASELINE config 4's placement), two ranks."""
+    W = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(W, _free_port(), 2, False, 1, 10, ret, True), nprocs=W, join=True)
+    _check_against_oracle(ret, W, 2, False, 1, 10)
 
 
 @pytest.mark.parametrize("fixed_len,weighted,dp_max_rows", [(1, False, 10), (0, True, 0)])

@@ -181,6 +181,36 @@ def test_planner_criteo_plans():
     assert rw_shard_rows(10, 3) == [4, 4, 2] and rw_shard_rows(5, 4) == [2, 2, 1, 0]
 
 
+def test_planner_host_offload_for_tables_beyond_hbm():
+    """BASELINE config 4 shape: > 2 TB of rows on 8 x 288 GB.  Row-wise shards alone exceed HBM, so the
+    largest tables move to host memory behind the HBM row cache (batched_fused_uvm_caching,
+    torchrec/distributed/embedding_types.py:57-76) until the plan fits; constraints can force a kernel."""
+    from torchrec_amd.distributed.planner import EmbeddingShardingPlanner, ParameterConstraints, Topology
+    from torchrec_amd.modules.embedding_configs import EmbeddingBagConfig
+
+    rows = [2_000_000_000, 1_500_000_000, 900_000_000, 40_000_000, 1000]  # 2.27 TB at D = 128 fp32
+    tables = [EmbeddingBagConfig(name=f"t{i}", embedding_dim=128, num_embeddings=r, feature_names=[f"c{i}"])
+              for i, r in enumerate(rows)]
+    topo = Topology(8)
+    plan = EmbeddingShardingPlanner(topo).plan_tables(tables)
+    assert [plan[f"t{i}"].sharding_type for i in range(5)] == ["row_wise"] * 3 + ["table_wise", "data_parallel"]
+    kernels = [plan[f"t{i}"].compute_kernel for i in range(3)]
+    assert kernels[0] == "batched_fused_uvm_caching" and kernels[2] == "batched_fused"
+    cap = topo.hbm_cap * (1 - topo.hbm_reserve_fraction)
+    hbm = 0.0
+    for i in range(3):
+        shard = -(-rows[i] // 8) * 512
+        hbm += shard * (topo.caching_ratio if kernels[i].endswith("caching") else 1.0)
+    assert hbm <= cap
+    # one GPU: a table larger than HBM is offloaded instead of failing
+    plan1 = EmbeddingShardingPlanner(Topology(1)).plan_tables(tables[:1])
+    assert plan1["t0"].sharding_type == "table_wise" and plan1["t0"].compute_kernel == "batched_fused_uvm_caching"
+    # forced kernel
+    forced = EmbeddingShardingPlanner(Topology(2), constraints={
+        "t3": ParameterConstraints(sharding_types=["row_wise"], compute_kernels=["batched_fused_uvm"])}).plan_tables(tables[3:])
+    assert forced["t3"].sharding_type == "row_wise" and forced["t3"].compute_kernel == "batched_fused_uvm"
+
+
 def _e2e_worker(rank, W, port, ret):
     """Full DLRM train steps through DistributedModelParallel + DDP + TrainPipelineSparseDist on
     gloo/CPU with the oracle TBE (tests/_oracle_tbe.py)."""

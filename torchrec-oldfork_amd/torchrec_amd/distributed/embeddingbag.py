@@ -63,14 +63,19 @@ def _default_tbe_factory(specs, ftm, pooling_mode, device, fused_params):
     from fbgemm_gpu.split_table_batched_embeddings_ops import (
         ComputeDevice, EmbeddingLocation, SplitTableBatchedEmbeddingBagsCodegen)
 
+    # compute kernel -> table location (embedding_types.py:57-76 compute_kernel_to_embedding_location)
+    loc = {"batched_fused_uvm": EmbeddingLocation.MANAGED, "batched_fused_uvm_caching": EmbeddingLocation.MANAGED_CACHING}
     return SplitTableBatchedEmbeddingBagsCodegen(
-        embedding_specs=[(r, d, EmbeddingLocation.DEVICE, ComputeDevice.CUDA) for r, d in specs],
+        embedding_specs=[(s[0], s[1], loc.get(s[2] if len(s) > 2 else "", EmbeddingLocation.DEVICE), ComputeDevice.CUDA)
+                         for s in specs],
         feature_table_map=ftm, pooling_mode=pooling_mode, device=device, **fused_params)
 
 
 class _LocalTable:
-    def __init__(self, cfg: EmbeddingBagConfig, local_rows: int, row_offset: int, row_wise: bool) -> None:
+    def __init__(self, cfg: EmbeddingBagConfig, local_rows: int, row_offset: int, row_wise: bool,
+                 compute_kernel: str = "batched_fused") -> None:
         self.cfg, self.local_rows, self.row_offset, self.row_wise = cfg, local_rows, row_offset, row_wise
+        self.compute_kernel = compute_kernel
 
 
 class SparseFeaturesDist:
@@ -299,9 +304,11 @@ class ShardedEmbeddingBagCollection(nn.Module):
             c = cfgs[t]
             if kind[t] == -1:
                 rows = rw_shard_rows(c.num_embeddings, W)[me]
-                self._local_tables.append(_LocalTable(c, rows, me * rw_block_size(c.num_embeddings, W), True))
+                self._local_tables.append(_LocalTable(c, rows, me * rw_block_size(c.num_embeddings, W), True,
+                                                      table_name_to_parameter_sharding[c.name].compute_kernel))
             else:
-                self._local_tables.append(_LocalTable(c, c.num_embeddings, 0, False))
+                self._local_tables.append(_LocalTable(c, c.num_embeddings, 0, False,
+                                                      table_name_to_parameter_sharding[c.name].compute_kernel))
             local_table_index[t] = len(self._local_tables) - 1
         ftm_local = [local_table_index[g_table[g]] for g in local_feats[me]]
         row_base = [self._local_tables[i].row_offset for i in ftm_local]
@@ -312,7 +319,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
         self._emb_module = None
         if self._local_tables:
             self._emb_module = factory(
-                [(max(lt.local_rows, 0), lt.cfg.embedding_dim) for lt in self._local_tables],
+                [(max(lt.local_rows, 0), lt.cfg.embedding_dim, lt.compute_kernel) for lt in self._local_tables],
                 ftm_local * W, pooling_type_to_pooling_mode(cfgs[0].pooling), dev, fused_params)
             if self._exchange:
                 self._emb_module.set_a2a_output_layout(W)

@@ -18,7 +18,11 @@ MAXIMUM number of (feature, dim) units any rank owns.  Three levers, in this ord
     (planner/partitioners.py:181-197 does this by estimated perf);
   * row-wise only where a table does not fit one GPU's HBM (or on request): with pooled output a
     row-wise feature makes EVERY rank send a partial pool to every peer, W x the bytes of a
-    table-wise feature, so it is a capacity tool here, not a balancing tool.
+    table-wise feature, so it is a capacity tool here, not a balancing tool;
+  * host offload where even the row-wise shards do not fit (BASELINE config 4: > 2 TB of rows on a
+    node with 8 x 288 GB): the largest tables go to pinned host memory behind the HBM row cache
+    (compute kernel `batched_fused_uvm_caching`, embedding_types.py:57-76; HBM cost = caching_ratio x
+    shard) until the rest fits.
 """
 from dataclasses import dataclass
 from typing import Dict, List, Optional
@@ -27,6 +31,15 @@ from ..modules.embedding_configs import EmbeddingBagConfig
 from .types import EmbeddingComputeKernel, ParameterSharding, ShardingPlan, ShardingType, ShardMetadata
 
 GiB = 1 << 30
+
+
+@dataclass
+class ParameterConstraints:
+    """User constraints on one table's plan (planner/types.py:247-258)."""
+
+    sharding_types: Optional[List[str]] = None
+    compute_kernels: Optional[List[str]] = None
+    caching_ratio: Optional[float] = None  # HBM cache size / table size for batched_fused_uvm_caching
 
 
 @dataclass
@@ -39,6 +52,8 @@ class Topology:
     hbm_mem_bw: float = 6.3e12
     intra_host_bw: float = 7 * 153e9
     hbm_reserve_fraction: float = 0.15  # activations, workspaces, dense model, allocator slack
+    ddr_cap: int = 1024 * 10**9         # host memory per rank for MANAGED* tables (planner/types.py:65-108 ddr_cap)
+    caching_ratio: float = 0.2          # planner/constants.py:26
 
 
 def rw_block_size(rows: int, world_size: int) -> int:
@@ -66,9 +81,14 @@ class EmbeddingShardingPlanner:
         cap = int(self.topology.hbm_cap * (1.0 - self.topology.hbm_reserve_fraction))
         size = {t.name: t.num_embeddings * t.embedding_dim * 4 for t in tables}
         by_size = sorted(tables, key=lambda t: (-size[t.name], t.name))
-        forced_rw = {n for n, c in self.constraints.items() if c == [ShardingType.ROW_WISE.value]}
-        forced_tw = {n for n, c in self.constraints.items() if c == [ShardingType.TABLE_WISE.value]}
-        forced_dp = {n for n, c in self.constraints.items() if c == [ShardingType.DATA_PARALLEL.value]}
+        st_of = {n: (c.sharding_types if isinstance(c, ParameterConstraints) else c) for n, c in self.constraints.items()}
+        ck_of = {n: c.compute_kernels for n, c in self.constraints.items()
+                 if isinstance(c, ParameterConstraints) and c.compute_kernels}
+        ratio_of = {n: c.caching_ratio for n, c in self.constraints.items()
+                    if isinstance(c, ParameterConstraints) and c.caching_ratio}
+        forced_rw = {n for n, c in st_of.items() if c == [ShardingType.ROW_WISE.value]}
+        forced_tw = {n for n, c in st_of.items() if c == [ShardingType.TABLE_WISE.value]}
+        forced_dp = {n for n, c in st_of.items() if c == [ShardingType.DATA_PARALLEL.value]}
         dp = set(forced_dp)
         if W > 1:
             for t in tables:
@@ -84,12 +104,34 @@ class EmbeddingShardingPlanner:
                 break
             if t.name not in forced_tw and t.name not in dp:
                 rw.add(t.name)
+        # compute kernel per table: forced by a constraint, else fused-in-HBM; when the row-wise shards alone
+        # exceed a rank's HBM budget the largest row-wise tables move to host memory behind the row cache
+        kernel_of: Dict[str, str] = {t.name: EmbeddingComputeKernel.BATCHED_FUSED.value for t in tables}
+        for n, ks in ck_of.items():
+            if n in kernel_of:
+                kernel_of[n] = ks[0]
+        uvm = {EmbeddingComputeKernel.BATCHED_FUSED_UVM.value, EmbeddingComputeKernel.BATCHED_FUSED_UVM_CACHING.value}
+
+        def hbm_bytes(t, shard_bytes):
+            k = kernel_of[t.name]
+            if k == EmbeddingComputeKernel.BATCHED_FUSED_UVM.value:
+                return 0
+            if k == EmbeddingComputeKernel.BATCHED_FUSED_UVM_CACHING.value:
+                return int(shard_bytes * ratio_of.get(t.name, self.topology.caching_ratio))
+            return shard_bytes
+
+        def rw_hbm(r):
+            return sum(hbm_bytes(t, rw_shard_rows(t.num_embeddings, W)[r] * t.embedding_dim * 4) for t in tables if t.name in rw)
+
+        for t in by_size:  # largest first
+            if max(rw_hbm(r) for r in range(W)) <= cap:
+                break
+            if t.name in rw and kernel_of[t.name] not in uvm and t.name not in ck_of:
+                kernel_of[t.name] = EmbeddingComputeKernel.BATCHED_FUSED_UVM_CACHING.value
         # greedy longest-processing-time fill of the table-wise tables
         units = [0.0] * W
-        mem = [sum(rw_shard_rows(t.num_embeddings, W)[r] * t.embedding_dim * 4 for t in tables if t.name in rw)
-               + sum(size[t.name] for t in tables if t.name in dp) for r in range(W)]
+        mem = [rw_hbm(r) + sum(size[t.name] for t in tables if t.name in dp) for r in range(W)]
         out: Dict[str, ParameterSharding] = {}
-        kernel = EmbeddingComputeKernel.BATCHED_FUSED.value
         for t in by_size:
             if t.name in dp:
                 out[t.name] = ParameterSharding(
@@ -103,17 +145,20 @@ class EmbeddingShardingPlanner:
                 for r in range(W):
                     spec.append(ShardMetadata([off, 0], [rows[r], t.embedding_dim], f"rank:{r}/cuda:{r}"))
                     off += rows[r]
-                out[t.name] = ParameterSharding(ShardingType.ROW_WISE.value, kernel, list(range(W)), spec)
+                out[t.name] = ParameterSharding(ShardingType.ROW_WISE.value, kernel_of[t.name], list(range(W)), spec)
                 continue
             cost = float(t.num_features() * t.embedding_dim)
             order = sorted(range(W), key=lambda r: (units[r], mem[r], r))
             placed = False
+            if W == 1 and kernel_of[t.name] not in uvm and t.name not in ck_of and mem[0] + size[t.name] > cap:
+                kernel_of[t.name] = EmbeddingComputeKernel.BATCHED_FUSED_UVM_CACHING.value  # one GPU: offload, not fail
+            need = hbm_bytes(t, size[t.name])
             for r in order:
-                if mem[r] + size[t.name] <= cap:
+                if mem[r] + need <= cap:
                     units[r] += cost
-                    mem[r] += size[t.name]
+                    mem[r] += need
                     out[t.name] = ParameterSharding(
-                        ShardingType.TABLE_WISE.value, kernel, [r],
+                        ShardingType.TABLE_WISE.value, kernel_of[t.name], [r],
                         [ShardMetadata([0, 0], [t.num_embeddings, t.embedding_dim], f"rank:{r}/cuda:{r}")])
                     placed = True
                     break
