@@ -349,3 +349,57 @@ def test_dlrm_train_world2_on_one_gpu_matches_world1(hip_graphs):
     for n in tabs1:
         t = int(n[1:])
         assert seen[n] in (E_ROWS[t], 2 * E_ROWS[t])
+
+
+# ---- sequence (unpooled) embeddings, table-wise + row-wise, two ranks on one GPU -------------------------
+
+def _seq_gpu_worker(rank, W, port, ret, row_wise):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=W)
+    try:
+        _stage_a2a_through_host()
+        from torchrec_amd.distributed.embedding import ShardedEmbeddingCollection
+        from torchrec_amd.distributed.types import ParameterSharding, ShardingEnv
+        from torchrec_amd.modules.embedding_configs import EmbeddingConfig
+        from torchrec_amd.sparse.jagged_tensor import KeyedJaggedTensor
+
+        rows, Dd, B = [30, 11, 19], 4, 5  # the shapes tests/test_sharded_gloo.py::_check_seq expects
+        keys = ["a", "b", "c"]
+        cfgs = [EmbeddingConfig(name=f"t{i}", embedding_dim=Dd, num_embeddings=rows[i], feature_names=[keys[i]]) for i in range(3)]
+        plan = {"t0": ParameterSharding("table_wise", "batched_fused", [1]),
+                "t1": ParameterSharding("table_wise", "batched_fused", [0]),
+                "t2": ParameterSharding("table_wise", "batched_fused", [1])}
+        for n in row_wise:
+            plan[n] = ParameterSharding("row_wise", "batched_fused", list(range(W)))
+        sec = ShardedEmbeddingCollection(cfgs, plan, ShardingEnv.from_process_group(dist.group.WORLD), {"learning_rate": 0.5}, dev)
+        init = [np.random.default_rng(100 + t).standard_normal((rows[t], Dd)).astype(np.float32) for t in range(3)]
+        r0 = sec.local_shard_row_offsets()
+        for name, w in sec.local_shards().items():
+            w.copy_(torch.from_numpy(init[int(name[1:])][r0[name]:r0[name] + w.shape[0]]))
+        rng = np.random.default_rng(7 + rank)
+        lengths = rng.integers(0, 4, size=3 * B).astype(np.int32)
+        vals = np.concatenate([rng.integers(0, rows[f], size=int(lengths[f * B:(f + 1) * B].sum())) for f in range(3)]).astype(np.int64)
+        kjt = KeyedJaggedTensor.from_lengths_sync(keys, torch.from_numpy(vals).to(dev), torch.from_numpy(lengths).to(dev))
+        out = sec(kjt).wait()
+        embs = {k: out[k].values() for k in keys}
+        cat = torch.cat([embs[k] for k in keys])
+        g = np.random.default_rng(70 + rank).standard_normal(tuple(cat.shape)).astype(np.float32)
+        cat.backward(torch.from_numpy(g).to(dev))
+        torch.cuda.synchronize()
+        ret[rank] = ({k: embs[k].detach().cpu().numpy().copy() for k in keys}, lengths, vals, g,
+                     {n: (w.detach().cpu().numpy().copy(), r0[n]) for n, w in sec.local_shards().items()})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("row_wise", [(), ("t0", "t2")])
+def test_sharded_sequence_embedding_world2_on_one_gpu(row_wise):
+    from test_sharded_gloo import _check_seq
+
+    W = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_seq_gpu_worker, args=(W, _free_port(), ret, row_wise), nprocs=W, join=True)
+    _check_seq(ret, W)

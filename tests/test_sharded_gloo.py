@@ -286,7 +286,7 @@ def test_dlrm_e2e_dmp_ddp_pipeline_world2():
     assert seen == rows
 
 
-def _seq_worker(rank, W, port, ret):
+def _seq_worker(rank, W, port, ret, row_wise=()):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=W)
@@ -305,11 +305,14 @@ def _seq_worker(rank, W, port, ret):
         plan = {"t0": ParameterSharding("table_wise", "batched_fused", [1]),
                 "t1": ParameterSharding("table_wise", "batched_fused", [0]),
                 "t2": ParameterSharding("table_wise", "batched_fused", [1])}
+        for n in row_wise:
+            plan[n] = ParameterSharding("row_wise", "batched_fused", list(range(W)))
         sec = ShardedEmbeddingCollection(cfgs, plan, ShardingEnv.from_process_group(dist.group.WORLD),
                                          {"learning_rate": 0.5}, torch.device("cpu"), oracle_seq_tbe_factory)
         init = [np.random.default_rng(100 + t).standard_normal((rows[t], D)).astype(np.float32) for t in range(3)]
+        r0 = sec.local_shard_row_offsets()
         for name, w in sec.local_shards().items():
-            w.copy_(torch.from_numpy(init[int(name[1:])]))
+            w.copy_(torch.from_numpy(init[int(name[1:])][r0[name]:r0[name] + w.shape[0]]))
         rng = np.random.default_rng(7 + rank)
         lengths = rng.integers(0, 4, size=3 * B).astype(np.int32)
         vals = np.concatenate([rng.integers(0, rows[f], size=int(lengths[f * B:(f + 1) * B].sum())) for f in range(3)]).astype(np.int64)
@@ -319,20 +322,29 @@ def _seq_worker(rank, W, port, ret):
         cat = torch.cat([embs[k] for k in keys])
         g = np.random.default_rng(70 + rank).standard_normal(tuple(cat.shape)).astype(np.float32)
         cat.backward(torch.from_numpy(g))
+        row0 = sec.local_shard_row_offsets()
         ret[rank] = ({k: embs[k].detach().numpy().copy() for k in keys}, lengths, vals, g,
-                     {n: w.clone().numpy() for n, w in sec.local_shards().items()})
+                     {n: (w.clone().numpy(), row0[n]) for n, w in sec.local_shards().items()})
     finally:
         dist.destroy_process_group()
 
 
-def test_sharded_sequence_embedding_world2():
+@pytest.mark.parametrize("row_wise", [(), ("t0",), ("t0", "t2"), ("t0", "t1", "t2")])
+def test_sharded_sequence_embedding_world2(row_wise):
+    """Table-wise, mixed and all row-wise (bucketize + unbucketize_permute) sequence sharding."""
     from oracle import oracle
 
     W = 2
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_seq_worker, args=(W, _free_port(), ret), nprocs=W, join=True)
-    rows, D, B = [30, 11, 19], 4, 5
+    mp.spawn(_seq_worker, args=(W, _free_port(), ret, row_wise), nprocs=W, join=True)
+    _check_seq(ret, W)
+
+
+def _check_seq(ret, W, D=4):
+    from oracle import oracle
+
+    rows, B = [30, 11, 19], 5
     init = [np.random.default_rng(100 + t).standard_normal((rows[t], D)).astype(np.float32) for t in range(3)]
     keys = ["a", "b", "c"]
     tabs = oracle.Tables(rows, [D] * 3)
@@ -356,9 +368,9 @@ def test_sharded_sequence_embedding_world2():
     g_vals, g_grad, g_len = np.concatenate(g_vals), np.concatenate(g_grad), np.concatenate(g_len)
     offs = np.concatenate([[0], np.cumsum(g_len)]).astype(np.int64)
     oracle.tbe_backward(tabs, g_vals, offs, g_grad, oracle.OPT_EXACT_SGD, 0.5, None, oracle.POOL_NONE)
-    seen = set()
+    seen = {"t0": 0, "t1": 0, "t2": 0}
     for r in range(W):
-        for name, w in ret[r][4].items():
-            np.testing.assert_allclose(w, tabs.weights[int(name[1:])], rtol=1e-5, atol=1e-5)
-            seen.add(name)
-    assert seen == {"t0", "t1", "t2"}
+        for name, (w, row0) in ret[r][4].items():
+            np.testing.assert_allclose(w, tabs.weights[int(name[1:])][row0:row0 + w.shape[0]], rtol=1e-5, atol=1e-5)
+            seen[name] += w.shape[0]
+    assert seen == {"t0": 30, "t1": 11, "t2": 19}

@@ -13,7 +13,12 @@ Data path per step (W ranks, rank r owns the features of its tables):
            per-feature JaggedTensors are sliced without a copy when features are sent in
            collection order;
   grads  : the same all-to-all reversed (x 1/W, comm_ops.py:704-706), then the fused TBE backward.
-Row-wise sequence sharding (bucketize + unbucketize_permute) is not implemented.
+
+Row-wise tables (sharding/rw_sequence_sharding.py): ids are bucketized by row block with
+`fbgemm.block_bucketize_sparse_features(sequence=True)` (embedding_sharding.py:121-184), bucket r goes
+to rank r, the looked-up rows come back in bucketized order and `unbucketize_permute` restores the
+caller's order with one index_select (dist_data.py:820-827).  Table-wise and row-wise tables of one
+collection run as two independent paths over disjoint features.
 """
 from typing import Any, Callable, Dict, List, Optional
 
@@ -24,6 +29,7 @@ from torch import nn
 from ..modules.embedding_configs import EmbeddingConfig
 from ..sparse.jagged_tensor import JaggedTensor, KeyedJaggedTensor
 from . import embeddingbag as _eb
+from .planner import rw_block_size, rw_shard_rows
 from .types import Awaitable, LazyAwaitable, NoWait, ParameterSharding, ShardingEnv, ShardingType
 
 
@@ -77,13 +83,19 @@ class ShardedEmbeddingCollection(nn.Module):
             for f in (c.feature_names or [c.name]):
                 self._feature_names.append(f)
                 g_table.append(t)
-        owner = []
+        owner = []  # owning rank of a table-wise table, -1 for a row-wise table
         for c in tables:
             ps = table_name_to_parameter_sharding[c.name]
-            if ps.sharding_type != ShardingType.TABLE_WISE.value:
-                raise NotImplementedError("sequence embeddings: only table_wise sharding is implemented")
-            owner.append(int(ps.ranks[0]))
+            if ps.sharding_type == ShardingType.TABLE_WISE.value:
+                owner.append(int(ps.ranks[0]))
+            elif ps.sharding_type == ShardingType.ROW_WISE.value:
+                owner.append(-1)
+            else:
+                raise NotImplementedError("sequence embeddings: table_wise and row_wise sharding are implemented")
         Fg = len(self._feature_names)
+        self._tw_feats = [g for g in range(Fg) if owner[g_table[g]] >= 0]
+        self._rw_feats = [g for g in range(Fg) if owner[g_table[g]] < 0]
+        self._init_row_wise(tables, g_table, fused_params, tbe_factory)
         self._local_feats = [[g for g in range(Fg) if owner[g_table[g]] == r] for r in range(self._W)]
         self._send_order = [g for lf in self._local_feats for g in lf]
         self._send_per_rank = [len(lf) for lf in self._local_feats]
@@ -102,12 +114,77 @@ class ShardedEmbeddingCollection(nn.Module):
             for t, w in zip(local_tables, self._emb_module.split_embedding_weights()):
                 w.uniform_(tables[t].get_weight_init_min(), tables[t].get_weight_init_max())
 
+    def _init_row_wise(self, tables, g_table, fused_params, tbe_factory) -> None:
+        W, me = self._W, self._me
+        self._rw_module = None
+        self._rw_table_ids: List[int] = []
+        for g in self._rw_feats:
+            if g_table[g] not in self._rw_table_ids:
+                self._rw_table_ids.append(g_table[g])
+        if not self._rw_feats:
+            return
+        ftm = [self._rw_table_ids.index(g_table[g]) for g in self._rw_feats]
+        self._rw_row0 = {t: me * rw_block_size(tables[t].num_embeddings, W) for t in self._rw_table_ids}
+        self._rw_blocks = [rw_block_size(tables[g_table[g]].num_embeddings, W) for g in self._rw_feats]
+        factory = tbe_factory or _default_seq_tbe_factory
+        self._rw_module = factory([(rw_shard_rows(tables[t].num_embeddings, W)[me], tables[t].embedding_dim)
+                                   for t in self._rw_table_ids], ftm * W, self._device, dict(fused_params or {}))
+        for t, w in zip(self._rw_table_ids, self._rw_module.split_embedding_weights()):
+            if w.numel():
+                w.uniform_(tables[t].get_weight_init_min(), tables[t].get_weight_init_max())
+
     def local_shards(self) -> Dict[str, torch.Tensor]:
-        if self._emb_module is None:
-            return {}
-        return {self._configs[t].name: w for t, w in zip(self._local_table_ids, self._emb_module.split_embedding_weights())}
+        """table name -> local weight shard (whole table if table-wise, this rank's row block if row-wise)."""
+        out: Dict[str, torch.Tensor] = {}
+        if self._emb_module is not None:
+            out.update({self._configs[t].name: w
+                        for t, w in zip(self._local_table_ids, self._emb_module.split_embedding_weights())})
+        if self._rw_module is not None:
+            out.update({self._configs[t].name: w
+                        for t, w in zip(self._rw_table_ids, self._rw_module.split_embedding_weights())})
+        return out
+
+    def local_shard_row_offsets(self) -> Dict[str, int]:
+        out = {self._configs[t].name: 0 for t in self._local_table_ids}
+        if self._rw_module is not None:
+            out.update({self._configs[t].name: self._rw_row0[t] for t in self._rw_table_ids})
+        return out
+
+    def _forward_row_wise(self, features: KeyedJaggedTensor) -> Dict[str, JaggedTensor]:
+        W, B, pg = self._W, features.stride(), self._pg
+        pos = {k: i for i, k in enumerate(features.keys())}
+        order = [pos[self._feature_names[g]] for g in self._rw_feats]
+        sub = features if order == list(range(len(features.keys()))) else features.permute(order)
+        lengths, values = sub.lengths(), sub.values()
+        Frw = len(self._rw_feats)
+        blocks = torch.tensor(self._rw_blocks, dtype=values.dtype, device=values.device)
+        nl, ni, _, _, unb = torch.ops.fbgemm.block_bucketize_sparse_features(lengths, values, False, True, blocks, W, None)
+        if W > 1:
+            val_in = nl.view(W, -1).sum(dim=1).cpu().tolist()  # host sync (dist_data.py:396-398)
+            recv_l = torch.empty(W * Frw * B, dtype=nl.dtype, device=nl.device)
+            dist.all_to_all_single(recv_l, nl, [Frw * B] * W, [Frw * B] * W, group=pg)
+            val_out = recv_l.view(W, -1).sum(dim=1).cpu().tolist()
+            recv_v = torch.empty(sum(val_out), dtype=ni.dtype, device=ni.device)
+            dist.all_to_all_single(recv_v, ni, val_out, val_in, group=pg)
+        else:
+            recv_l, recv_v, val_in, val_out = nl, ni, None, None
+        offsets = torch.ops.fbgemm.asynchronous_complete_cumsum(recv_l).long()
+        emb = self._rw_module(recv_v, offsets)
+        back = _SeqExchange.apply(emb, pg, val_out, val_in) if W > 1 else emb
+        rows = back.index_select(0, unb.long())  # bucketized order -> the caller's order
+        opk = sub.offset_per_key()
+        return {self._feature_names[g]: JaggedTensor(values=rows[opk[i]:opk[i + 1]], lengths=lengths[i * B:(i + 1) * B])
+                for i, g in enumerate(self._rw_feats)}
 
     def forward(self, features: KeyedJaggedTensor) -> Awaitable[Dict[str, JaggedTensor]]:
+        out: Dict[str, JaggedTensor] = {}
+        if self._rw_feats:
+            out.update(self._forward_row_wise(features))
+        if self._tw_feats:
+            out.update(self._forward_table_wise(features))
+        return NoWait({k: out[k] for k in self._feature_names})
+
+    def _forward_table_wise(self, features: KeyedJaggedTensor) -> Dict[str, JaggedTensor]:
         W, B, pg = self._W, features.stride(), self._pg
         pos = {k: i for i, k in enumerate(features.keys())}
         order = [pos[self._feature_names[g]] for g in self._send_order]
@@ -131,11 +208,12 @@ class ShardedEmbeddingCollection(nn.Module):
             offsets = torch.ops.fbgemm.asynchronous_complete_cumsum(recv_l).long()
             emb = self._emb_module(recv_v, offsets)
         else:
-            emb = torch.zeros((0, D), dtype=torch.float32, device=self._device)
+            # requires_grad: this rank must still take part in the backward exchange of the other ranks' rows
+            emb = torch.zeros((0, D), dtype=torch.float32, device=self._device, requires_grad=True)
         back = _SeqExchange.apply(emb, pg, val_out, val_in) if W > 1 else emb
         # `back` is ordered like `sent` (dest rank, its local features, samples)
         opk = sent.offset_per_key()
         out: Dict[str, JaggedTensor] = {}
         for i, g in enumerate(self._send_order):
             out[self._feature_names[g]] = JaggedTensor(values=back[opk[i]:opk[i + 1]], lengths=lengths[i * B:(i + 1) * B])
-        return NoWait({k: out[k] for k in self._feature_names})
+        return out
