@@ -76,18 +76,28 @@ __global__ __launch_bounds__(256, 2) void interaction_fwd_kernel(const float* __
   const int nvec = R * (D / 4);
   const int stride_b = gridDim.x * 4;
 
-  (void)MAXV;
   for (int b = blockIdx.x * 4 + wave; b < B; b += stride_b) {
-    // global -> LDS tile (row 0 = dense[b], rows 1..F = sparse[b]).  A register-prefetch of the
-    // next sample was tried and lost 50 %: hipcc serialises it behind vmcnt(0); latency is hidden
-    // by the second wave on the SIMD instead.
-    for (int v = lane; v < nvec; v += kWave) {
-      const float4 x = ld4(XLoader<D>::src(dense, sparse, b, F, v));
-      const int r = v >> LOG_V;
-      const int c = (v & ((1 << LOG_V) - 1)) * 4;
-      float2* dst = reinterpret_cast<float2*>(xs + r * XS + c);
-      dst[0] = make_float2(x.x, x.y);
-      dst[1] = make_float2(x.z, x.w);
+    // global -> LDS tile (row 0 = dense[b], rows 1..F = sparse[b]).  All of the sample's 16-B loads
+    // are issued before the first LDS store (fully unrolled, MAXV registers): a plain load->store loop
+    // exposes one HBM latency per iteration (14 per sample at F = 26, D = 128) and ran 3.3x off the
+    // HBM roofline.  (A register-prefetch of the NEXT sample was tried and lost: hipcc serialises it
+    // behind vmcnt(0); cross-sample latency is hidden by the second wave on the SIMD instead.)
+    float4 pre[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int v = lane + i * kWave;
+      if (v < nvec) pre[i] = ld4(XLoader<D>::src(dense, sparse, b, F, v));
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int v = lane + i * kWave;
+      if (v < nvec) {
+        const int r = v >> LOG_V;
+        const int c = (v & ((1 << LOG_V) - 1)) * 4;
+        float2* dst = reinterpret_cast<float2*>(xs + r * XS + c);
+        dst[0] = make_float2(pre[i].x, pre[i].y);
+        dst[1] = make_float2(pre[i].z, pre[i].w);
+      }
     }
     wave_lds_fence();
     f32x4 acc00 = {0.f, 0.f, 0.f, 0.f}, acc01 = acc00, acc11 = acc00;
