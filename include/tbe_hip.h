@@ -343,6 +343,15 @@ int tbe_dlrm_interaction_backward_f32(const float* dense, const float* sparse,
                                       const float* grad_out, int32_t B, int32_t F, int32_t D,
                                       float* grad_dense, float* grad_sparse, void* stream);
 
+/* ReLU backward + bias gradient of one MLP layer in one pass (torchrec/modules/mlp.py:14-170 Perceptron
+ * trained through autograd: threshold_backward + sum(0)):
+ *   grad_in[b, c] = act[b, c] > 0 ? grad_out[b, c] : 0;   bias_grad[c] = sum_b grad_in[b, c]
+ * [B, N] row-major, N a multiple of 4, 16-B aligned; column sums in fixed order (deterministic). */
+size_t tbe_relu_backward_bias_grad_workspace_bytes(int64_t B, int32_t N);
+int tbe_relu_backward_bias_grad_f32(const float* grad_out, const float* act, int64_t B, int32_t N,
+                                    float* grad_in, float* bias_grad, void* workspace,
+                                    size_t workspace_bytes, void* stream);
+
 /* torch.ops.fbgemm.jagged_2d_to_dense (examples/bert4rec/models/bert4rec.py:394-400):
  * values [N, D] + offsets [B+1] -> dense [B, max_L, D], zero padded / truncated. */
 int tbe_jagged_2d_to_dense_f32(const float* values, const int64_t* offsets, int32_t B,

@@ -26,3 +26,20 @@ def test_perceptron_matches_plain_torch(B, I, O):
     torch.testing.assert_close(x.grad, x2.grad, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(p._linear.weight.grad, w2.grad, rtol=2e-4, atol=2e-3)
     torch.testing.assert_close(p._linear.bias.grad, b2.grad, rtol=2e-4, atol=2e-3)
+
+
+@pytest.mark.parametrize("B,N", [(65536, 1024), (8192, 128), (1000, 52), (3, 256), (70, 4)])
+def test_relu_backward_bias_grad_one_pass(B, N):
+    """csrc/mlp_epilogue.hip: masked gradient is bit-exact (a select), column sums to fp32 summation-order
+    tolerance against a float64 sum; two runs are bitwise identical (fixed order, no atomics)."""
+    import torchrec_amd.distributed._device_ops  # noqa: F401
+
+    torch.manual_seed(1)
+    gy = torch.randn(B, N, device="cuda")
+    act = torch.relu(torch.randn(B, N, device="cuda"))
+    gx, gb = torch.ops.tbe_hip.relu_backward_bias_grad(gy, act)
+    ref = gy * (act > 0)
+    assert torch.equal(gx, ref)
+    torch.testing.assert_close(gb, ref.double().sum(0).float(), rtol=1e-4, atol=1e-3)
+    gx2, gb2 = torch.ops.tbe_hip.relu_backward_bias_grad(gy, act)
+    assert torch.equal(gb, gb2) and torch.equal(gx, gx2)

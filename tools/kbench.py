@@ -75,6 +75,26 @@ def main():
         o = mod(batches[i % len(batches)], offsets)
         o.backward(grad)
 
+    import ctypes
+
+    from fbgemm_gpu import _lib
+    lib = _lib.load()
+    for i in range(3):
+        fwdbwd(i)
+    torch.cuda.synchronize()
+    lib.tbe_profile_enable(1)
+    tot, n = ctypes.c_double(0.0), ctypes.c_int64(0)
+    for slot in range(4):
+        lib.tbe_profile_read(slot, ctypes.byref(tot), ctypes.byref(n))
+    for i in range(args.iters):
+        fwdbwd(i)
+    torch.cuda.synchronize()
+    names = ["fwd kernel", "bwd_update kernel", "bwd apply (update+fixup)", "bwd prepare (linearize+sort)"]
+    for slot in range(4):
+        lib.tbe_profile_read(slot, ctypes.byref(tot), ctypes.byref(n))
+        if n.value:
+            print(f"  [events] {names[slot]}: {tot.value / n.value * 1e3:.1f} us avg over {n.value}", flush=True)
+    lib.tbe_profile_enable(0)
     ms_fb = timeit(fwdbwd, args.iters)
     bwd_bytes = B * (F * D * 4 + F * 16 + 2 * F * D * 4)
     ms_b = ms_fb - ms_f

@@ -13,7 +13,25 @@ _def.define("pooled_exchange_pack(Tensor grad, Tensor feat_out_col, Tensor feat_
             "Tensor slab_offset, Tensor slab_stride, int numel, bool vec, float scale) -> Tensor")
 _def.define("a2a_pooled_unpack(Tensor recv, Tensor dim_sum_per_rank, int B_local, int D_total, bool vec, float scale) -> Tensor")
 _def.define("a2a_pooled_pack(Tensor grad, Tensor dim_sum_per_rank, bool vec, float scale) -> Tensor")
+_def.define("relu_backward_bias_grad(Tensor grad_out, Tensor act) -> (Tensor, Tensor)")
 _impl = torch.library.Library("tbe_hip", "IMPL", "CUDA")
+
+
+def _relu_backward_bias_grad(grad_out, act):
+    """(grad_out * (act > 0), its column sums) in one pass (csrc/mlp_epilogue.hip)."""
+    from fbgemm_gpu._lib import workspace
+
+    dev = require_gpu(grad_out, act)
+    grad_out, act = grad_out.contiguous(), act.contiguous()
+    B, N = grad_out.shape
+    gx = torch.empty_like(grad_out)
+    gb = torch.empty(N, dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        ws = workspace(lib.tbe_relu_backward_bias_grad_workspace_bytes(B, N), dev)
+        check(lib.tbe_relu_backward_bias_grad_f32(ptr(grad_out), ptr(act), B, N, ptr(gx), ptr(gb), ptr(ws), ws.numel(),
+                                                  stream_ptr(dev)), "tbe_relu_backward_bias_grad_f32")
+    return gx, gb
 
 
 def _simple_unpack(recv, dims, B_local, D_total, vec, scale):
@@ -63,6 +81,7 @@ def _pack(grad, feat_out_col, feat_src, feat_slab_col, slab_offset, slab_stride,
     return send
 
 
+_impl.impl("relu_backward_bias_grad", _relu_backward_bias_grad)
 _impl.impl("pooled_exchange_unpack", _unpack)
 _impl.impl("pooled_exchange_pack", _pack)
 _impl.impl("a2a_pooled_unpack", _simple_unpack)

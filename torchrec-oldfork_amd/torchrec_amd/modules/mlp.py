@@ -30,9 +30,15 @@ class _LinearSplitKWgrad(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
+        gb = None
         if ctx.fuse_relu:
             x, weight, out = ctx.saved_tensors
-            gy = torch.ops.aten.threshold_backward(gy.contiguous(), out, 0.0)
+            if ctx.has_bias and gy.dtype == torch.float32 and out.shape[1] % 4 == 0:
+                # ReLU backward + bias gradient in one pass over [B, out] (csrc/mlp_epilogue.hip)
+                from ..distributed import _device_ops  # noqa: F401  (registers torch.ops.tbe_hip.*)
+                gy, gb = torch.ops.tbe_hip.relu_backward_bias_grad(gy, out)
+            else:
+                gy = torch.ops.aten.threshold_backward(gy.contiguous(), out, 0.0)
         else:
             x, weight = ctx.saved_tensors
             gy = gy.contiguous()
@@ -43,7 +49,8 @@ class _LinearSplitKWgrad(torch.autograd.Function):
             gw = torch.bmm(gy.view(c, B // c, -1).transpose(1, 2), x.view(c, B // c, -1)).sum(dim=0)
         else:
             gw = gy.t() @ x
-        gb = gy.sum(dim=0) if ctx.has_bias else None
+        if gb is None and ctx.has_bias:
+            gb = gy.sum(dim=0)
         return gx, gw, gb, None, None
 
 
