@@ -4,8 +4,12 @@
  *   combined = cat(dense.unsqueeze(1), sparse); inter = bmm(combined, combined^T);
  *   out = cat(dense, inter[:, triu_indices(F+1, F+1, offset=1)]).
  * Pinned against the reference module itself by tests/golden/dlrm_small.npz (make_golden.py).
- * Sums are k-ordered fmaf chains starting from 0 — the arithmetic v_mfma_f32_16x16x4_f32
- * performs — so the HIP kernel can be compared bit for bit.
+ * Sums are fmaf chains starting from 0 — the arithmetic v_mfma_f32_16x16x4_f32 performs — walked
+ * in the order the HIP kernels feed the matrix core, so they can be compared bit for bit: the
+ * backward in ascending k; the forward over columns 16 s + 4 q + e in (s, e, q) order (its MFMA
+ * operands are 16-B global loads: lane quarter q holds columns 16 s + 4 q .. + 3 of segment s;
+ * csrc/dlrm_interaction.hip).  D must be a multiple of 16 for that order; other D fall back to
+ * ascending k (no HIP kernel exists for them).
  */
 #include <math.h>
 #include <stdint.h>
@@ -26,7 +30,16 @@ void oracle_interaction_forward(const float* dense, const float* sparse, int32_t
         const float* xi = row_of(dense, sparse, b, F, D, i);
         const float* xj = row_of(dense, sparse, b, F, D, j);
         float acc = 0.f;
-        for (int32_t k = 0; k < D; ++k) acc = fmaf(xi[k], xj[k], acc);
+        if (D % 16 == 0) {
+          for (int32_t s = 0; s < D / 16; ++s)
+            for (int32_t e = 0; e < 4; ++e)
+              for (int32_t q = 0; q < 4; ++q) {
+                const int32_t k = 16 * s + 4 * q + e;
+                acc = fmaf(xi[k], xj[k], acc);
+              }
+        } else {
+          for (int32_t k = 0; k < D; ++k) acc = fmaf(xi[k], xj[k], acc);
+        }
         o[D + p++] = acc;
       }
   }

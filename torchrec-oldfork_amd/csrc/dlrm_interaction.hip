@@ -55,61 +55,59 @@ struct XLoader {
   }
 };
 
+// Forward.  MFMA operands come straight from 16-B global loads, no LDS operand tile: lane (r, q)
+// (r = lane & 15, q = lane >> 4) of v_mfma_f32_16x16x4_f32 supplies element k = q of row r, and any
+// assignment of columns to (step, k) slots is valid as long as both operands use the same one.  With
+// column(segment s, element e, quarter q) = 16 s + 4 q + e a lane's operands for row r are the float4s
+// X[r][16 s + 4 q .. +3], s = 0 .. D/16-1: D/16 coalescable 16-B loads per row tile, all issued before
+// the first MFMA.  The summation order over columns is therefore (s, e, q) — the oracle walks the
+// same order (oracle/dlrm_oracle.c), so results stay bit-exact.  LDS only re-stages the 351 pair
+// products for a coalesced store; occupancy is bound by VGPRs (4 waves / SIMD at D = 128), not LDS.
 template <int D>
-__global__ __launch_bounds__(256, 2) void interaction_fwd_kernel(const float* __restrict__ dense,
-                                                                 const float* __restrict__ sparse,
-                                                                 float* __restrict__ out, int B, int F) {
+__global__ __launch_bounds__(256, (D <= 128 ? 4 : 2)) void interaction_fwd_kernel(const float* __restrict__ dense,
+                                                                                  const float* __restrict__ sparse,
+                                                                                  float* __restrict__ out, int B, int F) {
   extern __shared__ float smem[];
-  constexpr int XS = D + 2;  // row stride: (2*row + k) % 32 distinct over a half-wave => no bank conflict
-  constexpr int LOG_V = XLoader<D>::LOG_V;
-  constexpr int MAXV = (32 * D / 4 + kWave - 1) / kWave;  // float4 per lane for up to 32 rows
+  constexpr int NS = D / 16;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int R = F + 1;
   const int P = R * (R - 1) / 2;
   const int OUT = D + P;
-  const int per_wave = 32 * XS + ((P + 3) & ~3);
-  float* xs = smem + wave * per_wave;
-  float* zs = xs + 32 * XS;
+  float* zs = smem + wave * ((P + 3) & ~3);
   const int r16 = lane & 15;
   const int kq = lane >> 4;
-  const int nvec = R * (D / 4);
+  // rows >= R alias row R-1: their products only reach Z rows / columns >= R, which are never stored
+  const int row0 = min(r16, R - 1);
+  const int row1 = min(16 + r16, R - 1);
   const int stride_b = gridDim.x * 4;
-
   for (int b = blockIdx.x * 4 + wave; b < B; b += stride_b) {
-    // global -> LDS tile (row 0 = dense[b], rows 1..F = sparse[b]).  All of the sample's 16-B loads
-    // are issued before the first LDS store (fully unrolled, MAXV registers): a plain load->store loop
-    // exposes one HBM latency per iteration (14 per sample at F = 26, D = 128) and ran 3.3x off the
-    // HBM roofline.  (A register-prefetch of the NEXT sample was tried and lost: hipcc serialises it
-    // behind vmcnt(0); cross-sample latency is hidden by the second wave on the SIMD instead.)
-    float4 pre[MAXV];
+    const float* x0 = (row0 == 0 ? dense + static_cast<int64_t>(b) * D
+                                 : sparse + (static_cast<int64_t>(b) * F + (row0 - 1)) * D) + 4 * kq;
+    const float* x1 = sparse + (static_cast<int64_t>(b) * F + (row1 - 1)) * D + 4 * kq;  // row1 >= 1 when R >= 2
+    float4 xa[NS], xb[NS];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      const int v = lane + i * kWave;
-      if (v < nvec) pre[i] = ld4(XLoader<D>::src(dense, sparse, b, F, v));
-    }
+    for (int s = 0; s < NS; ++s) xa[s] = ld4(x0 + 16 * s);
+    if (R > 16) {
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      const int v = lane + i * kWave;
-      if (v < nvec) {
-        const int r = v >> LOG_V;
-        const int c = (v & ((1 << LOG_V) - 1)) * 4;
-        float2* dst = reinterpret_cast<float2*>(xs + r * XS + c);
-        dst[0] = make_float2(pre[i].x, pre[i].y);
-        dst[1] = make_float2(pre[i].z, pre[i].w);
-      }
+      for (int s = 0; s < NS; ++s) xb[s] = ld4(x1 + 16 * s);
+    } else {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) xb[s] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    wave_lds_fence();
+    float4 dpass = make_float4(0.f, 0.f, 0.f, 0.f);  // out[:, :D] = dense[b]
+    if (lane < D / 4) dpass = ld4(dense + static_cast<int64_t>(b) * D + lane * 4);
     f32x4 acc00 = {0.f, 0.f, 0.f, 0.f}, acc01 = acc00, acc11 = acc00;
-    const float* pa0 = xs + r16 * XS + kq;
-    const float* pa1 = xs + (16 + r16) * XS + kq;
-#pragma unroll 8
-    for (int k0 = 0; k0 < D; k0 += 4) {
-      const float a0 = pa0[k0];
-      const float a1 = pa1[k0];  // rows >= R hold stale data: they only reach Z rows/cols >= R, never stored
-      acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, a0, acc00, 0, 0, 0);
-      acc01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, a1, acc01, 0, 0, 0);
-      acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, a1, acc11, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const float a0[4] = {xa[s].x, xa[s].y, xa[s].z, xa[s].w};
+      const float a1[4] = {xb[s].x, xb[s].y, xb[s].z, xb[s].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], a0[e], acc00, 0, 0, 0);
+        acc01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], a1[e], acc01, 0, 0, 0);
+        acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], a1[e], acc11, 0, 0, 0);
+      }
     }
     // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
 #pragma unroll
@@ -122,9 +120,14 @@ __global__ __launch_bounds__(256, 2) void interaction_fwd_kernel(const float* __
     }
     wave_lds_fence();
     float* orow = out + static_cast<int64_t>(b) * OUT;
-    for (int c = lane; c < D; c += kWave) orow[c] = xs[c];
+    if (lane < D / 4) {  // row stride OUT = D + P is not a multiple of 4 in general: scalar stores
+      orow[lane * 4 + 0] = dpass.x;
+      orow[lane * 4 + 1] = dpass.y;
+      orow[lane * 4 + 2] = dpass.z;
+      orow[lane * 4 + 3] = dpass.w;
+    }
     for (int p = lane; p < P; p += kWave) orow[D + p] = zs[p];
-    wave_lds_fence();  // xs/zs are rewritten by the next sample
+    wave_lds_fence();  // zs is rewritten by the next sample
   }
 }
 
@@ -298,19 +301,11 @@ extern "C" int tbe_dlrm_interaction_forward_f32(const float* dense, const float*
   TBE_REQUIRE(((reinterpret_cast<uintptr_t>(dense) | reinterpret_cast<uintptr_t>(sparse)) & 15) == 0,
               "tbe_dlrm_interaction_forward_f32: inputs must be 16-B aligned");
   const int R = F + 1, P = R * (R - 1) / 2;
-  const size_t lds = 4 * (static_cast<size_t>(32) * (D + 2) + ((P + 3) & ~3)) * sizeof(float);
+  const size_t lds = 4 * static_cast<size_t>((P + 3) & ~3) * sizeof(float);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const dim3 grid(interaction_grid(B));
-  static bool attr_set = false;
-  if (!attr_set) {  // dynamic LDS above 64 KB must be opted into
-    const size_t big = 4 * (static_cast<size_t>(32) * (256 + 2) + 496) * sizeof(float);
-    if (!reserve_lds(interaction_fwd_kernel<128>, big) || !reserve_lds(interaction_fwd_kernel<256>, big) ||
-        !reserve_lds(interaction_fwd_kernel<64>, big)) {
-      set_error("tbe_dlrm_interaction_forward_f32: cannot reserve LDS");
-      return TBE_ERR_LAUNCH;
-    }
-    attr_set = true;
-  }
+  // persistent-style: 4 workgroups per CU (2 at D = 256), each wave strides over samples
+  const int64_t want = (static_cast<int64_t>(B) + 3) / 4;
+  const dim3 grid(static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(want, 256 * (D <= 128 ? 4 : 2)))));
 #define TBE_IF(DD) hipLaunchKernelGGL(interaction_fwd_kernel<DD>, grid, dim3(256), lds, st, dense, sparse, out, B, F)
   switch (D) {
     case 16: TBE_IF(16); break;
