@@ -65,7 +65,7 @@ def _data(W, fixed_len, weighted, seed=11):
     return per_rank, init
 
 
-def _build_sharded(W, backend_env, weighted, n_rw, dp_max_rows, offload=False):
+def _build_sharded(W, backend_env, weighted, n_rw, dp_max_rows, offload=False, adagrad=False):
     from torchrec_amd.distributed.embeddingbag import ShardedEmbeddingBagCollection
     from torchrec_amd.distributed.planner import EmbeddingShardingPlanner, ParameterConstraints, Topology
     from torchrec_amd.modules.embedding_configs import EmbeddingBagConfig
@@ -82,6 +82,9 @@ def _build_sharded(W, backend_env, weighted, n_rw, dp_max_rows, offload=False):
     plan = EmbeddingShardingPlanner(Topology(W), constraints=cons, num_row_wise=n_rw,
                                     dp_max_rows=dp_max_rows).plan_tables(tables)
     fused = {"learning_rate": LR, "cache_sets": 2} if offload else {"learning_rate": LR}
+    if adagrad:
+        from fbgemm_gpu.split_embedding_configs import EmbOptimType
+        fused.update({"optimizer": EmbOptimType.EXACT_ROWWISE_ADAGRAD, "eps": 1e-3})
     sebc = ShardedEmbeddingBagCollection(ebc, plan, backend_env, fused, torch.device("cuda", 0))
     return keys, plan, sebc
 
@@ -121,7 +124,7 @@ def _run_rank(sebc, keys, per_rank, init, rank, W, fixed_len, weighted):
     return vals_out.detach().cpu().numpy().copy(), shards
 
 
-def _worker(rank, W, port, fixed_len, weighted, n_rw, dp_max_rows, ret, offload=False):
+def _worker(rank, W, port, fixed_len, weighted, n_rw, dp_max_rows, ret, offload=False, adagrad=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
@@ -132,8 +135,12 @@ def _worker(rank, W, port, fixed_len, weighted, n_rw, dp_max_rows, ret, offload=
 
         per_rank, init = _data(W, fixed_len, weighted)
         keys, plan, sebc = _build_sharded(W, ShardingEnv.from_process_group(dist.group.WORLD), weighted, n_rw, dp_max_rows,
-                                          offload)
+                                          offload, adagrad)
         out, shards = _run_rank(sebc, keys, per_rank, init, rank, W, fixed_len, weighted)
+        if adagrad:  # per-table row-wise state of the local shards (batched_embedding_kernel.py:133-148)
+            states = sebc._emb_module.split_optimizer_states()
+            for lt, st in zip(sebc._local_tables, states):
+                shards[lt.cfg.name] = shards[lt.cfg.name] + (st[0].detach().cpu().numpy().copy(),)
         if offload:
             assert plan["t3"].compute_kernel == "batched_fused_uvm_caching" and sebc._emb_module._cache is not None
         ret[rank] = (out, shards, {n: p.sharding_type for n, p in plan.items()})
@@ -141,7 +148,7 @@ def _worker(rank, W, port, fixed_len, weighted, n_rw, dp_max_rows, ret, offload=
         dist.destroy_process_group()
 
 
-def _check_against_oracle(ret, W, fixed_len, weighted, n_rw, dp_max_rows):
+def _check_against_oracle(ret, W, fixed_len, weighted, n_rw, dp_max_rows, adagrad=False):
     from oracle import oracle
 
     per_rank, init = _data(W, fixed_len, weighted)
@@ -167,12 +174,27 @@ def _check_against_oracle(ret, W, fixed_len, weighted, n_rw, dp_max_rows):
     g_vals, g_w = cat(1), (cat(2) if weighted else None)
     g_grad = np.concatenate([per_rank[r][3] for r in range(W)], axis=0) / W
     g_offs = np.concatenate([[0], np.cumsum(g_len)]).astype(np.int64)
-    oracle.tbe_backward(tabs, g_vals, g_offs, g_grad, oracle.OPT_EXACT_SGD, LR, g_w)
+    s0 = [np.zeros(r, dtype=np.float32) for r in ROWS]
+    if adagrad:
+        # replicated tables are dense parameters stepped by plain SGD in this test; the fused optimizer owns the rest
+        sgd_tabs = oracle.Tables(ROWS, [D] * F)
+        for t in range(F):
+            sgd_tabs.weights[t][...] = init[t]
+        oracle.tbe_backward(sgd_tabs, g_vals, g_offs, g_grad, oracle.OPT_EXACT_SGD, LR, g_w)
+        oracle.tbe_backward(tabs, g_vals, g_offs, g_grad, oracle.OPT_EXACT_ROWWISE_ADAGRAD, LR, g_w, eps=1e-3, state0=s0)
+        for t in range(F):
+            if kinds[f"t{t}"] == "data_parallel":
+                tabs.weights[t][...] = sgd_tabs.weights[t]
+    else:
+        oracle.tbe_backward(tabs, g_vals, g_offs, g_grad, oracle.OPT_EXACT_SGD, LR, g_w)
     seen = {t: 0 for t in range(F)}
     for r in range(W):
-        for name, (w, row0) in ret[r][1].items():
+        for name, shard in ret[r][1].items():
+            w, row0 = shard[0], shard[1]
             t = int(name[1:])
-            np.testing.assert_allclose(w, tabs.weights[t][row0:row0 + w.shape[0]], rtol=2e-5, atol=2e-5)
+            np.testing.assert_allclose(w, tabs.weights[t][row0:row0 + w.shape[0]], rtol=3e-5, atol=3e-5)
+            if adagrad and len(shard) > 2:  # sharding invariance of the fused optimizer state (test_fused_optim.py:201-306)
+                np.testing.assert_allclose(shard[2], s0[t][row0:row0 + w.shape[0]], rtol=3e-5, atol=3e-5)
             seen[t] += w.shape[0]
     for t in range(F):
         assert seen[t] == ROWS[t] * (W if kinds[f"t{t}"] == "data_parallel" else 1)
@@ -205,6 +227,17 @@ def _rccl_worker(rank, port, fixed_len, weighted, dp_max_rows, ret):
         ret[0] = (out, shards, {n: p.sharding_type for n, p in plan.items()})
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_rw,offload", [(0, False), (2, False), (1, True)])
+def test_sharded_world2_fused_rowwise_adagrad(n_rw, offload):
+    """The reference's fused-optimizer test (torchrec/distributed/tests/test_fused_optim.py:60-140, 201-306:
+    RW / TW x EXACT_ROWWISE_ADAGRAD): weights AND optimizer state of the shards equal the unsharded run —
+    here with the real kernels, incl. row-wise shards behind the HBM row cache."""
+    W = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(W, _free_port(), 2, False, n_rw, 10, ret, offload, True), nprocs=W, join=True)
+    _check_against_oracle(ret, W, 2, False, n_rw, 10, adagrad=True)
 
 
 def test_sharded_world2_with_host_offloaded_tables():
