@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--num-batches", type=int, default=16, help="distinct pre-generated batches")
+    ap.add_argument("--tuned-gemms", choices=["on", "off"], default="on",
+                    help="replay the recorded hipBLASLt / rocBLAS kernel choice per GEMM shape (torchrec_amd/tuning)")
     ap.add_argument("--hip-graphs", choices=["auto", "on", "off"], default="auto",
                     help="replay the collective-free dense segments from HIP graphs (auto: N = 1 and batch <= 16384, "
                          "where host launches show; never under DDP)")
@@ -98,6 +100,10 @@ def main():
         env = ShardingEnv.from_local(1, 0)
     if args.global_batch % world:
         raise SystemExit("global batch must divide evenly over the ranks")
+    tuned = False
+    if args.tuned_gemms == "on" and os.environ.get("PYTORCH_TUNABLEOP_TUNING", "0") != "1":
+        from torchrec_amd.tuning import enable_tuned_gemms
+        tuned = enable_tuned_gemms()
     B_local = args.global_batch // world
     rows = [min(r, args.row_cap) if args.row_cap else r for r in CRITEO_1TB_ROWS]
 
@@ -223,7 +229,7 @@ def main():
             # the reference's only published number is 5 497 159.68 samples/s on 8 x A100-40GB
             # (examples/dlrm/README.MD:45, real Criteo data, end to end) — comparable at N = 8 only
             "vs_baseline": round(value / 5497159.68, 3) if world == 8 else None,
-            "dtype": "f32", "data": "synthetic", "hip_graphs": hip_graphs,
+            "dtype": "f32", "data": "synthetic", "hip_graphs": hip_graphs, "tuned_gemms": tuned,
             "config": {"workload": "DLRM Criteo-1TB shape: 26 tables (177.9M rows, 84.85 GiB fp32, D=128), 13 dense, "
                                    "pooling factor 1, dense 512-256-128, over 1024-1024-512-256-1, fused exact SGD",
                        "global_batch": args.global_batch, "local_batch": B_local,

@@ -63,3 +63,19 @@ def test_enum_surface_used_by_reference():
     assert {e.name for e in PoolingMode} == {"SUM", "MEAN", "NONE"}
     assert {"FP32", "FP16", "INT8", "INT4", "INT2"} <= {e.name for e in SparseType}
     assert {"EXACT_SGD", "EXACT_ROWWISE_ADAGRAD", "ADAM"} <= {e.name for e in EmbOptimType}
+
+
+def test_recorded_gemm_choices_file_is_well_formed():
+    """torchrec_amd/tuning/gemm_gfx950_dlrm.csv: validators + one line per (op, shape) with a solution name."""
+    import os
+
+    import torchrec_amd.tuning as tuning
+
+    lines = [ln.strip() for ln in open(tuning._FILE) if ln.strip()]
+    validators = [ln for ln in lines if ln.startswith("Validator,")]
+    rows = [ln.split(",") for ln in lines if not ln.startswith("Validator,")]
+    assert any("gfx950" in v for v in validators)
+    assert rows and all(len(r) == 4 and r[2].startswith("Gemm_") and float(r[3]) > 0 for r in rows)
+    assert len({(r[0], r[1]) for r in rows}) == len(rows)
+    assert any("_65536_" in r[1] for r in rows) and any("_8192_" in r[1] for r in rows)
+    assert os.path.basename(tuning._FILE) == "gemm_gfx950_dlrm.csv"

@@ -43,3 +43,35 @@ def test_relu_backward_bias_grad_one_pass(B, N):
     torch.testing.assert_close(gb, ref.double().sum(0).float(), rtol=1e-4, atol=1e-3)
     gx2, gb2 = torch.ops.tbe_hip.relu_backward_bias_grad(gy, act)
     assert torch.equal(gb, gb2) and torch.equal(gx, gx2)
+
+
+def test_tuned_gemm_replay_keeps_results():
+    """torchrec_amd/tuning: replaying the recorded hipBLASLt / rocBLAS kernel choice changes which fp32 GEMM
+    kernel runs, not what is computed."""
+    import torch.cuda.tunable as tunable
+
+    from torchrec_amd.modules.mlp import Perceptron
+    from torchrec_amd.tuning import enable_tuned_gemms
+
+    torch.manual_seed(0)
+    p = Perceptron(479, 1024, device=torch.device("cuda"))
+    x = torch.randn(8192, 479, device="cuda")
+    g = torch.randn(8192, 1024, device="cuda")
+
+    def run():
+        xi = x.clone().requires_grad_()
+        p.zero_grad()
+        y = p(xi)
+        y.backward(g)
+        return y.detach().clone(), xi.grad.clone(), p._linear.weight.grad.clone()
+
+    base = run()
+    ok = enable_tuned_gemms()
+    try:
+        assert ok, "the recorded GEMM choices must load on the image they were recorded on"
+        assert tunable.is_enabled() and not tunable.tuning_is_enabled()
+        tuned = run()
+    finally:
+        tunable.enable(False)
+    for a, b in zip(base, tuned):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=2e-3)

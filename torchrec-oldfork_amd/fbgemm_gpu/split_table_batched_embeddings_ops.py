@@ -665,9 +665,7 @@ class _DenseLookupInto(torch.autograd.Function):
         indices, offsets, psw = ctx.saved_tensors
         module = ctx.module
         grad_w = torch.zeros_like(module.weights)
-        base = grad_w.data_ptr()
-        ptrs = [base + 4 * module.weights_offsets[t] for t in module.feature_table_map]
-        state0 = torch.tensor(ptrs, dtype=torch.int64).to(grad_w.device)
+        state0 = module._dense_grad_ptrs(grad_w)
         opt = OptimizerArgs(_OPT_DENSE_GRAD, 0.0, 0.0, 0.0, 0.0, 0.0, 1)
         module._backward_impl(grad_out, indices, offsets, psw, ctx.B, opt, state0_override=state0, layout=ctx.layout)
         return (grad_out, grad_w) + (None,) * 7
@@ -897,9 +895,7 @@ class _DenseLookup(torch.autograd.Function):
         indices, offsets, psw = ctx.saved_tensors
         module = ctx.module
         grad_w = torch.zeros_like(module.weights)
-        base = grad_w.data_ptr()
-        ptrs = [base + 4 * module.weights_offsets[t] for t in module.feature_table_map]
-        state0 = torch.tensor(ptrs, dtype=torch.int64).to(grad_w.device)
+        state0 = module._dense_grad_ptrs(grad_w)
         opt = OptimizerArgs(_OPT_DENSE_GRAD, 0.0, 0.0, 0.0, 0.0, 0.0, 1)
         module._backward_impl(grad_out, indices, offsets, psw, ctx.B, opt, state0_override=state0)
         return grad_w, None, None, None, None, None
@@ -928,6 +924,15 @@ class DenseTableBatchedEmbeddingBagsCodegen(_TBEBase):
 
     def _flat_weights(self, placement: str) -> torch.Tensor:
         return self.weights if placement == "dev" else self._empty
+
+    def _dense_grad_ptrs(self, grad_w: torch.Tensor) -> torch.Tensor:
+        """Per-feature base addresses inside a dense gradient buffer, computed on the device (a
+        host-built table would cost a blocking H2D copy in every backward)."""
+        rel = getattr(self, "_dense_rel", None)
+        if rel is None or rel.device != grad_w.device:
+            rel = torch.tensor([4 * self.weights_offsets[t] for t in self.feature_table_map], dtype=torch.int64).to(grad_w.device)
+            self._dense_rel = rel
+        return rel + grad_w.data_ptr()
 
     def _storage_key(self):
         return (self.weights.data_ptr(), 0)
