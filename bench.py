@@ -184,8 +184,8 @@ def main():
     bwd_bytes_all_distinct = feat_units * args.global_batch * (D * 4 + 16 + 2 * D * 4)
     kern = {}
     for name, slot, nbytes in (("tbe_fwd_short_kernel", 0, fwd_bytes), ("bwd_update_kernel", 1, bwd_bytes),
-                               ("tbe_backward_apply(update+fixup)", 2, bwd_bytes),
-                               ("tbe_backward_prepare(linearize+sort, side stream)", 3, 0.0)):
+                               ("tbe_backward whole call (fused: linearize+sort+update+fixup; two-phase: update+fixup)", 2, bwd_bytes),
+                               ("tbe_backward_prepare (linearize+sort)", 3, 0.0)):
         tot_ms, n = prof[slot]
         if n:
             avg_ms = tot_ms / max(args.steps, 1)  # per step (one launch per step at N = 1)

@@ -457,8 +457,12 @@ class ShardedEmbeddingBagCollection(nn.Module):
         if fixed is not None and len(set(fixed)) == 1 and fixed[0] > 0:
             L = fixed[0]
             nkeys = len(features.keys())
-            send_v = features.values().view(nkeys, B * L).index_select(0, order_t)
-            send_w = weights.view(nkeys, B * L).index_select(0, order_t) if weights is not None else None
+            if order == list(range(nkeys)):  # already in send order: no gather
+                send_v = features.values().view(nkeys, B * L)
+                send_w = weights.view(nkeys, B * L) if weights is not None else None
+            else:
+                send_v = features.values().view(nkeys, B * L).index_select(0, order_t)
+                send_w = weights.view(nkeys, B * L).index_select(0, order_t) if weights is not None else None
             in_splits = [n * B * L for n in self._send_feats_per_rank]
             out_splits = [self._F_local * B * L] * W
             if self._exchange:
