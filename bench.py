@@ -66,8 +66,8 @@ def parse():
     ap.add_argument("--tuned-gemms", choices=["on", "off"], default="on",
                     help="replay the recorded hipBLASLt / rocBLAS kernel choice per GEMM shape (torchrec_amd/tuning)")
     ap.add_argument("--hip-graphs", choices=["auto", "on", "off"], default="auto",
-                    help="replay the collective-free dense segments from HIP graphs (auto: N = 1 and batch <= 16384, "
-                         "where host launches show; never under DDP)")
+                    help="replay the collective-free dense segments from HIP graphs (auto: per-rank batch <= 32768, "
+                         "where host launches show)")
     return ap.parse_args()
 
 
@@ -87,7 +87,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # TORCHREC_AMD_FORCE_EXCHANGE=1: rehearsal of the N > 1 data path on one GPU (a one-rank RCCL group)
-    rehearse = world == 1 and os.environ.get("TORCHREC_AMD_FORCE_EXCHANGE") == "1"
+    # (TORCHREC_AMD_FORCE_DDP=1 additionally wraps the dense modules in DistributedDataParallel over that group)
+    rehearse = world == 1 and (os.environ.get("TORCHREC_AMD_FORCE_EXCHANGE") == "1"
+                               or os.environ.get("TORCHREC_AMD_FORCE_DDP") == "1")
     if world > 1 or rehearse:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
@@ -114,9 +116,16 @@ def main():
     train_model = DLRMTrain(embedding_bag_collection=ebc, dense_in_features=INT_FEATURE_COUNT,
                             dense_arch_layer_sizes=[512, 256, 128],
                             over_arch_layer_sizes=[1024, 1024, 512, 256, 1], dense_device=dev)
+    hip_graphs = args.hip_graphs == "on" or (args.hip_graphs == "auto" and B_local <= 32768)
     model = DistributedModelParallel(
         module=train_model, env=env, device=dev,
-        sharders=[EmbeddingBagCollectionSharder(fused_params={"learning_rate": args.lr})])
+        sharders=[EmbeddingBagCollectionSharder(fused_params={"learning_rate": args.lr})],
+        init_data_parallel=False)
+    if hip_graphs:
+        # HIP-graph replay of the collective-free dense segments; captured before DistributedDataParallel
+        # wraps the dense modules (distributed/train_pipeline.py explains why)
+        train_model.capture_hip_graphs(B_local)
+    model.init_data_parallel()
     dense_params = dict(model.named_parameters())
     optimizer = CombinedOptimizer([
         model.fused_optimizer,
@@ -129,8 +138,7 @@ def main():
                             manual_seed=1234 + rank, num_generated_batches=args.num_batches, device=dev,
                             zipf_alpha=args.zipf or None)
     it = iter(data)
-    hip_graphs = world == 1 and (args.hip_graphs == "on" or (args.hip_graphs == "auto" and B_local <= 16384))
-    pipe = TrainPipelineSparseDist(model, optimizer, dev, hip_graphs=hip_graphs)
+    pipe = TrainPipelineSparseDist(model, optimizer, dev)
     model.train()
     lib = _lib.load()
 

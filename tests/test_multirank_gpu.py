@@ -276,7 +276,7 @@ def _e2e_batches(W):
     return out
 
 
-def _e2e_model(env, dev, dp_max_rows):
+def _e2e_model(env, dev, dp_max_rows, graph_batch=0):
     from torchrec_amd.distributed.embeddingbag import EmbeddingBagCollectionSharder
     from torchrec_amd.distributed.model_parallel import DistributedModelParallel
     from torchrec_amd.distributed.planner import EmbeddingShardingPlanner, Topology
@@ -293,7 +293,11 @@ def _e2e_model(env, dev, dp_max_rows):
     tm = DLRMTrain(ebc, 13, [64, D], [96, 32, 1], dense_device=dev)
     model = DistributedModelParallel(tm, env=env, device=dev, sharders=[EmbeddingBagCollectionSharder({"learning_rate": E_LR})],
                                      planner=EmbeddingShardingPlanner(Topology(env.world_size), num_row_wise=1,
-                                                                      dp_max_rows=dp_max_rows))
+                                                                      dp_max_rows=dp_max_rows),
+                                     init_data_parallel=not graph_batch)
+    if graph_batch:  # HIP-graph segments must be captured BEFORE DistributedDataParallel wraps the dense modules
+        tm.capture_hip_graphs(graph_batch)
+        model.init_data_parallel()
     opt = CombinedOptimizer([model.fused_optimizer,
                              KeyedOptimizerWrapper(dict(model.named_parameters()), lambda p: torch.optim.SGD(p, lr=E_LR))])
     return keys, model, opt
@@ -347,17 +351,20 @@ def _e2e_worker(rank, W, port, ret, hip_graphs=False):
         _stage_a2a_through_host()
         from torchrec_amd.distributed.types import ShardingEnv
 
-        keys, model, opt = _e2e_model(ShardingEnv.from_process_group(dist.group.WORLD), dev, dp_max_rows=10)
+        keys, model, opt = _e2e_model(ShardingEnv.from_process_group(dist.group.WORLD), dev, dp_max_rows=10,
+                                      graph_batch=E_B if hip_graphs else 0)
         _e2e_init_tables(model)
-        ret[rank] = _e2e_run(model, opt, keys, _e2e_batches(W), rank, W, dev, hip_graphs)
+        ret[rank] = _e2e_run(model, opt, keys, _e2e_batches(W), rank, W, dev, False)
+        assert (model.module._graphs is not None) == bool(hip_graphs)
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("hip_graphs", [False, True])
 def test_dlrm_train_world2_on_one_gpu_matches_world1(hip_graphs):
-    """hip_graphs=True is declined under DistributedDataParallel (train_pipeline.py): the loop must run
-    eagerly and give the same result."""
+    """hip_graphs=True: the dense segments replay from HIP graphs under DistributedDataParallel — captured
+    BEFORE the DDP wrap (capturing a backward graph over DDP-managed parameters crashes in
+    hipStreamEndCapture on this stack; the pipeline's lazy capture is therefore declined under DDP)."""
     W = 2
     ret = mp.Manager().dict()
     mp.spawn(_e2e_worker, args=(W, _free_port(), ret, hip_graphs), nprocs=W, join=True)

@@ -3,6 +3,7 @@ replaces every EmbeddingBagCollection in `module` by a ShardedEmbeddingBagCollec
 the plan (planner on rank 0 semantics: the plan is a pure function of the configs, so every
 rank computes the same one — no broadcast_object_list needed), and wraps the remaining dense
 parameters in DistributedDataParallel (model_parallel.py:84-111) when world_size > 1."""
+import os
 from typing import Dict, Iterator, List, Optional, Tuple
 
 import torch
@@ -59,7 +60,9 @@ class DistributedModelParallel(nn.Module):
         for p in dense:
             if p.device != self.device:
                 raise RuntimeError("dense parameters must live on the DMP device")
-        if self._env.world_size > 1 and dense:
+        # TORCHREC_AMD_FORCE_DDP=1: rehearsal switch — wrap in DistributedDataParallel even on a one-rank group
+        force = os.environ.get("TORCHREC_AMD_FORCE_DDP", "0") == "1" and self._env.process_group is not None
+        if (self._env.world_size > 1 or force) and dense:
             # sharded tables (buffers of the TBE modules) differ per rank and must neither be
             # broadcast at DDP construction nor reduced (model_parallel.py:84-100 does the same)
             ignore = []
@@ -76,6 +79,9 @@ class DistributedModelParallel(nn.Module):
                 process_group=self._env.process_group, gradient_as_bucket_view=True, broadcast_buffers=False,
                 static_graph=True)
         self._ddp_wrapped = True
+
+    def is_data_parallel_wrapped(self) -> bool:
+        return isinstance(self._dmp_wrapped_module, DistributedDataParallel)
 
     @staticmethod
     def _dense_named_parameters(m: nn.Module) -> Iterator[Tuple[str, nn.Parameter]]:

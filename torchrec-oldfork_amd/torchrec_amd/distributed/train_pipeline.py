@@ -41,11 +41,12 @@ class TrainPipelineSparseDist:
         self._model, self._optimizer, self._device = model, optimizer, device
         # hip_graphs: capture the model's collective-free dense segments as HIP graphs on the first
         # batch (models that offer `capture_hip_graphs(batch_size)`, distributed/hip_graph.py)
-        # Declined under DistributedDataParallel (world_size > 1): replaying the segments' backward under
-        # DDP's bucket-view gradient hooks crashed in the 2-rank rehearsal (tests/test_multirank_gpu.py),
-        # and the measured gain at the 8-GPU per-rank batch is only ~4 % (the step is GEMM-bound there).
+        # Under DistributedDataParallel the capture must happen BEFORE the DDP wrap (capturing a backward
+        # graph over DDP-managed parameters crashes in hipStreamEndCapture on this stack): build the
+        # DistributedModelParallel with init_data_parallel=False, call capture_hip_graphs(batch), then
+        # init_data_parallel() — bench.py does.  The lazy capture below is for un-wrapped models only.
         self._hip_graphs = hip_graphs and device.type == "cuda"
-        if isinstance(model, DistributedModelParallel) and model._env.world_size > 1:
+        if isinstance(model, DistributedModelParallel) and model.is_data_parallel_wrapped():
             self._hip_graphs = False
         use_streams = device.type == "cuda"
         self._memcpy_stream = torch.cuda.Stream(device) if use_streams else None
