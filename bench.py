@@ -88,6 +88,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     # TORCHREC_AMD_FORCE_EXCHANGE=1: rehearsal of the N > 1 data path on one GPU (a one-rank RCCL group)
     # (TORCHREC_AMD_FORCE_DDP=1 additionally wraps the dense modules in DistributedDataParallel over that group)
+    # TORCHREC_AMD_FORCE_DP=1 replicates the tiny tables as an N > 1 plan does.
     rehearse = world == 1 and (os.environ.get("TORCHREC_AMD_FORCE_EXCHANGE") == "1"
                                or os.environ.get("TORCHREC_AMD_FORCE_DDP") == "1")
     if world > 1 or rehearse:

@@ -24,6 +24,7 @@ MAXIMUM number of (feature, dim) units any rank owns.  Three levers, in this ord
     (compute kernel `batched_fused_uvm_caching`, embedding_types.py:57-76; HBM cost = caching_ratio x
     shard) until the rest fits.
 """
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional
 
@@ -90,7 +91,9 @@ class EmbeddingShardingPlanner:
         forced_tw = {n for n, c in st_of.items() if c == [ShardingType.TABLE_WISE.value]}
         forced_dp = {n for n, c in st_of.items() if c == [ShardingType.DATA_PARALLEL.value]}
         dp = set(forced_dp)
-        if W > 1:
+        # TORCHREC_AMD_FORCE_DP=1: rehearsal switch — replicate the tiny tables even on one rank, so that a
+        # one-rank run executes the replicated-table path of an N > 1 plan
+        if W > 1 or os.environ.get("TORCHREC_AMD_FORCE_DP", "0") == "1":
             for t in tables:
                 if t.num_embeddings <= self.dp_max_rows and t.name not in forced_rw and t.name not in forced_tw:
                     dp.add(t.name)
