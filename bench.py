@@ -125,7 +125,10 @@ def main():
     if hip_graphs:
         # HIP-graph replay of the collective-free dense segments; captured before DistributedDataParallel
         # wraps the dense modules (distributed/train_pipeline.py explains why)
-        train_model.capture_hip_graphs(B_local)
+        # With a process group the segments' gradients travel through ONE flat buffer that is all-reduced
+        # per segment, instead of DDP's per-parameter bucket copies (models/dlrm.py)
+        train_model.capture_hip_graphs(B_local, flat_grads=env.process_group is not None,
+                                       process_group=env.process_group)
     model.init_data_parallel()
     dense_params = dict(model.named_parameters())
     optimizer = CombinedOptimizer([

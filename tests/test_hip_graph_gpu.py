@@ -9,7 +9,7 @@ import _paths  # noqa: F401
 pytestmark = pytest.mark.gpu
 
 
-def _train(hip_graphs: bool, steps: int = 6):
+def _train(hip_graphs: bool, steps: int = 6, flat: bool = False):
     from torchrec_amd.datasets.random import RandomRecDataset
     from torchrec_amd.distributed.embeddingbag import EmbeddingBagCollectionSharder
     from torchrec_amd.distributed.model_parallel import DistributedModelParallel
@@ -33,7 +33,9 @@ def _train(hip_graphs: bool, steps: int = 6):
     opt = CombinedOptimizer([model.fused_optimizer,
                              KeyedOptimizerWrapper(dict(model.named_parameters()), lambda p: torch.optim.SGD(p, lr=lr))])
     data = RandomRecDataset(keys, B, rows, manual_seed=5, num_generated_batches=4, num_batches=steps + 2, device=dev)
-    pipe = TrainPipelineSparseDist(model, opt, dev, hip_graphs=hip_graphs)
+    if flat:  # gradients of the graphed segments through one flat buffer (what bench.py does for N > 1)
+        tm.capture_hip_graphs(B, flat_grads=True)
+    pipe = TrainPipelineSparseDist(model, opt, dev, hip_graphs=hip_graphs and not flat)
     model.train()
     it = iter(data)
     losses = [float(pipe.progress(it)[0].detach()) for _ in range(steps)]
@@ -44,9 +46,10 @@ def _train(hip_graphs: bool, steps: int = 6):
     return losses, params, shards, model, pipe, data
 
 
-def test_graphed_train_loop_matches_eager():
+@pytest.mark.parametrize("flat", [False, True])
+def test_graphed_train_loop_matches_eager(flat):
     l0, p0, s0, *_ = _train(False)
-    l1, p1, s1, model, pipe, data = _train(True)
+    l1, p1, s1, model, pipe, data = _train(True, flat=flat)
     np.testing.assert_allclose(l1, l0, rtol=1e-5, atol=1e-6)
     for k in p0:
         np.testing.assert_allclose(p1[k], p0[k], rtol=1e-4, atol=1e-6, err_msg=k)

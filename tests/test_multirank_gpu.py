@@ -276,7 +276,7 @@ def _e2e_batches(W):
     return out
 
 
-def _e2e_model(env, dev, dp_max_rows, graph_batch=0):
+def _e2e_model(env, dev, dp_max_rows, graph_batch=0, flat=False, seed=0):
     from torchrec_amd.distributed.embeddingbag import EmbeddingBagCollectionSharder
     from torchrec_amd.distributed.model_parallel import DistributedModelParallel
     from torchrec_amd.distributed.planner import EmbeddingShardingPlanner, Topology
@@ -285,7 +285,7 @@ def _e2e_model(env, dev, dp_max_rows, graph_batch=0):
     from torchrec_amd.modules.embedding_modules import EmbeddingBagCollection
     from torchrec_amd.optim.keyed import CombinedOptimizer, KeyedOptimizerWrapper
 
-    torch.manual_seed(0)
+    torch.manual_seed(seed)
     keys = [f"c{i}" for i in range(len(E_ROWS))]
     tables = [EmbeddingBagConfig(name=f"t{i}", embedding_dim=D, num_embeddings=E_ROWS[i], feature_names=[keys[i]])
               for i in range(len(E_ROWS))]
@@ -296,7 +296,7 @@ def _e2e_model(env, dev, dp_max_rows, graph_batch=0):
                                                                       dp_max_rows=dp_max_rows),
                                      init_data_parallel=not graph_batch)
     if graph_batch:  # HIP-graph segments must be captured BEFORE DistributedDataParallel wraps the dense modules
-        tm.capture_hip_graphs(graph_batch)
+        tm.capture_hip_graphs(graph_batch, flat_grads=flat, process_group=env.process_group)
         model.init_data_parallel()
     opt = CombinedOptimizer([model.fused_optimizer,
                              KeyedOptimizerWrapper(dict(model.named_parameters()), lambda p: torch.optim.SGD(p, lr=E_LR))])
@@ -352,7 +352,10 @@ def _e2e_worker(rank, W, port, ret, hip_graphs=False):
         from torchrec_amd.distributed.types import ShardingEnv
 
         keys, model, opt = _e2e_model(ShardingEnv.from_process_group(dist.group.WORLD), dev, dp_max_rows=10,
-                                      graph_batch=E_B if hip_graphs else 0)
+                                      graph_batch=E_B if hip_graphs else 0, flat=(hip_graphs == "flat"),
+                                      seed=0 if rank == 0 else 77)  # ranks > 0 must receive rank 0's dense weights
+        if hip_graphs == "flat":
+            assert len(model.module.flat_grad_parameters()) > 0
         _e2e_init_tables(model)
         ret[rank] = _e2e_run(model, opt, keys, _e2e_batches(W), rank, W, dev, False)
         assert (model.module._graphs is not None) == bool(hip_graphs)
@@ -360,11 +363,14 @@ def _e2e_worker(rank, W, port, ret, hip_graphs=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("hip_graphs", [False, True])
+@pytest.mark.parametrize("hip_graphs", [False, True, "flat"])
 def test_dlrm_train_world2_on_one_gpu_matches_world1(hip_graphs):
     """hip_graphs=True: the dense segments replay from HIP graphs under DistributedDataParallel — captured
     BEFORE the DDP wrap (capturing a backward graph over DDP-managed parameters crashes in
-    hipStreamEndCapture on this stack; the pipeline's lazy capture is therefore declined under DDP)."""
+    hipStreamEndCapture on this stack; the pipeline's lazy capture is therefore declined under DDP).
+    "flat": the graphed segments' gradients additionally travel through one flat all-reduced buffer instead
+    of DDP (models/dlrm.py capture_hip_graphs(flat_grads=True)); ranks start from different dense weights
+    and must end identical (the rank-0 broadcast DDP would have done)."""
     W = 2
     ret = mp.Manager().dict()
     mp.spawn(_e2e_worker, args=(W, _free_port(), ret, hip_graphs), nprocs=W, join=True)

@@ -47,6 +47,14 @@ class _Replay(torch.autograd.Function):
             if s is not None and g is not None and g.data_ptr() != s.data_ptr():
                 s.copy_(g)
         seg.bwd_graph.replay()
+        if seg.param_grad_sinks is not None:
+            # parameter gradients were written (scaled) into the caller's flat buffer inside the graph;
+            # autograd gets none, the owner of the buffer is told they are ready
+            n_in = seg.n_inputs
+            out = (None,) + tuple(g.detach() if g is not None else None for g in seg.static_grad_inputs[:n_in])
+            if seg.after_backward is not None:
+                seg.after_backward()
+            return out + (None,) * (len(seg.static_grad_inputs) - n_in)
         return (None,) + tuple(g.detach() if g is not None else None for g in seg.static_grad_inputs)
 
 
@@ -71,6 +79,8 @@ class GraphedSegment(nn.Module):
         self.bwd_graph: Optional[torch.cuda.CUDAGraph] = None
         self.static_grad_outputs: List[Optional[torch.Tensor]] = []
         self.static_grad_inputs: List[Optional[torch.Tensor]] = []
+        self.param_grad_sinks: Optional[List[torch.Tensor]] = None
+        self.after_backward = None  # callable run right after the backward replay (param_grad_sinks mode)
         dev = self.static_inputs[0].device
         self._stream = torch.cuda.Stream(dev)
         # ---- warm-up (lazy workspaces, GEMM heuristics) on the capture stream ---------------------
@@ -97,9 +107,13 @@ class GraphedSegment(nn.Module):
     def static_input(self, i: int) -> torch.Tensor:
         return self.static_inputs[i]
 
-    def capture_backward(self, grad_output_buffers: Optional[Sequence[Optional[torch.Tensor]]] = None) -> None:
+    def capture_backward(self, grad_output_buffers: Optional[Sequence[Optional[torch.Tensor]]] = None,
+                         param_grad_sinks: Optional[Sequence[torch.Tensor]] = None, sink_scale: float = 1.0) -> None:
         """Captures d(outputs)/d(inputs, parameters).  `grad_output_buffers[i]` lets a downstream
-        segment's static input-gradient buffer double as this segment's output-gradient buffer."""
+        segment's static input-gradient buffer double as this segment's output-gradient buffer.
+        `param_grad_sinks[j]` (one per parameter, in `parameters()` order): the graph itself writes
+        `sink_scale * d/d(param j)` there — e.g. views of one flat buffer that is all-reduced as a whole —
+        and autograd receives no parameter gradients from this segment."""
         outs = self.static_outputs
         bufs = list(grad_output_buffers) if grad_output_buffers is not None else [None] * len(outs)
         self.static_grad_outputs = [
@@ -112,6 +126,16 @@ class GraphedSegment(nn.Module):
         with torch.cuda.graph(self.bwd_graph, pool=self._pool, stream=self._stream, capture_error_mode="thread_local"):
             grads = torch.autograd.grad(need, targets, [g for g in self.static_grad_outputs if g is not None],
                                         allow_unused=True)
+            if param_grad_sinks is not None:
+                n_in = sum(1 for x in self.static_inputs if x.requires_grad)
+                if len(param_grad_sinks) != len(self._params):
+                    raise ValueError("one gradient sink per parameter")
+                for g, sink in zip(grads[n_in:], param_grad_sinks):
+                    if g is None:
+                        sink.zero_()
+                    else:
+                        torch.mul(g, sink_scale, out=sink)
+                self.param_grad_sinks = list(param_grad_sinks)
         it = iter(grads)
         self.static_grad_inputs = [next(it) if x.requires_grad else None for x in self.static_inputs]
         self.static_grad_inputs += list(it)  # parameter gradients, in self._params order

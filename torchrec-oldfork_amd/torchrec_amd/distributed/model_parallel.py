@@ -62,6 +62,17 @@ class DistributedModelParallel(nn.Module):
                 raise RuntimeError("dense parameters must live on the DMP device")
         # TORCHREC_AMD_FORCE_DDP=1: rehearsal switch — wrap in DistributedDataParallel even on a one-rank group
         force = os.environ.get("TORCHREC_AMD_FORCE_DDP", "0") == "1" and self._env.process_group is not None
+        # parameters whose gradients a model reduces itself through a flat buffer (DLRMTrain.capture_hip_graphs(
+        # flat_grads=True)) stay out of DDP
+        flat_ids = {id(p) for p in (m.flat_grad_parameters() if hasattr(m, "flat_grad_parameters") else [])}
+        if flat_ids and self._env.world_size > 1:
+            # what DDP's constructor does for its own parameters: every rank starts from rank 0's values
+            with torch.no_grad():
+                for p in dense:
+                    if id(p) in flat_ids:
+                        dist.broadcast(p.data, src=dist.get_global_rank(self._env.process_group, 0)
+                                       if self._env.process_group is not None else 0, group=self._env.process_group)
+        dense = [p for p in dense if id(p) not in flat_ids]
         if (self._env.world_size > 1 or force) and dense:
             # sharded tables (buffers of the TBE modules) differ per rank and must neither be
             # broadcast at DDP construction nor reduced (model_parallel.py:84-100 does the same)
@@ -73,6 +84,7 @@ class DistributedModelParallel(nn.Module):
                     for n, _ in nn.Module.named_parameters(sub):
                         if not n.startswith("_dp_module."):  # replicated tables ARE reduced by DDP
                             ignore.append(f"{path}.{n}" if path else n)
+            ignore += [n for n, p in m.named_parameters() if id(p) in flat_ids]
             DistributedDataParallel._set_params_and_buffers_to_ignore_for_model(m, ignore)
             self._dmp_wrapped_module = DistributedDataParallel(
                 m, device_ids=[self.device.index] if self.device.type == "cuda" else None,

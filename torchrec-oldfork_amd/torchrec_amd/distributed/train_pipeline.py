@@ -126,6 +126,9 @@ class TrainPipelineSparseDist:
                     self._start_data_dist(self._batch_ip1)
         if self._model.training:
             torch.sum(losses, dim=0).backward()
+            root = self._model.module if isinstance(self._model, DistributedModelParallel) else self._model
+            if hasattr(root, "finish_dense_grads"):
+                root.finish_dense_grads()  # flat-buffer gradient all-reduce of graphed segments (models/dlrm.py)
             self._optimizer.step()
         self._batch_i, self._batch_ip1 = self._batch_ip1, self._batch_ip2
         return losses, output

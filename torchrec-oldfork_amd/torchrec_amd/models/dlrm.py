@@ -185,10 +185,17 @@ class DLRMTrain(nn.Module):
         self.loss_fn = nn.BCEWithLogitsLoss()
         self._graphs = None  # (batch size, bottom-MLP segment, head segment)
 
-    def capture_hip_graphs(self, batch_size: int) -> None:
+    def capture_hip_graphs(self, batch_size: int, flat_grads: bool = False, process_group=None) -> None:
         """Captures the two collective-free dense segments of a train step — bottom MLP; interaction
         + top MLP + loss — as HIP graphs for this per-rank batch size (distributed/hip_graph.py).
-        Steps with another batch size, eval mode or no_grad run eagerly as before."""
+        Steps with another batch size, eval mode or no_grad run eagerly as before.
+
+        flat_grads: the backward graphs write the parameter gradients, already divided by the world
+        size, into ONE flat buffer; each segment's slice is all-reduced (asynchronously, as soon as its
+        backward replay is enqueued) over `process_group`, and `finish_dense_grads()` attaches the
+        slices as `.grad`.  This replaces DistributedDataParallel for these parameters (16 per-parameter
+        bucket copies + hook overhead per step — the per-rank step of an N > 1 run is host-bound);
+        DistributedModelParallel.init_data_parallel() keeps them out of DDP."""
         from ..distributed.hip_graph import GraphedSegment
 
         m = self.model
@@ -203,10 +210,57 @@ class DLRMTrain(nn.Module):
                    torch.randn(B, F, D, device=dev).requires_grad_(True),
                    torch.randint(0, 2, (B,), device=dev).float()],
             input_buffers=[g_dense.static_outputs[0], None, None], pool=g_dense._pool)
-        g_head.capture_backward()
+        head_sinks = dense_sinks = None
+        scale = 1.0
+        if flat_grads:
+            import torch.distributed as dist
+
+            world = dist.get_world_size(process_group) if process_group is not None else 1
+            scale = 1.0 / world
+            n_head = sum(q.numel() for q in g_head._params)
+            n_dense = sum(q.numel() for q in g_dense._params)
+            flat = torch.zeros(n_head + n_dense, dtype=torch.float32, device=dev)
+
+            def views(params, off):
+                out = []
+                for q in params:
+                    out.append(flat[off:off + q.numel()].view_as(q))
+                    off += q.numel()
+                return out
+
+            head_sinks, dense_sinks = views(g_head._params, 0), views(g_dense._params, n_head)
+            state = {"flat": flat, "params": list(g_head._params) + list(g_dense._params),
+                     "views": head_sinks + dense_sinks, "works": [], "pg": process_group, "world": world}
+
+            def reducer(lo, hi):
+                def start():
+                    if state["world"] > 1:
+                        state["works"].append(dist.all_reduce(flat[lo:hi], group=state["pg"], async_op=True))
+                return start
+
+            g_head.after_backward = reducer(0, n_head)            # the head's backward runs first
+            g_dense.after_backward = reducer(n_head, n_head + n_dense)
+            object.__setattr__(self, "_flat_dense", state)
+        g_head.capture_backward(param_grad_sinks=head_sinks, sink_scale=scale)
         # the head's gradient w.r.t. the bottom-MLP output doubles as the bottom segment's grad_output buffer
-        g_dense.capture_backward([g_head.static_grad_inputs[0]])
+        g_dense.capture_backward([g_head.static_grad_inputs[0]], param_grad_sinks=dense_sinks, sink_scale=scale)
         object.__setattr__(self, "_graphs", (B, g_dense, g_head))  # not sub-modules: state_dict keys unchanged
+
+    def flat_grad_parameters(self) -> List[nn.Parameter]:
+        """Parameters whose gradients travel through the flat buffer (kept out of DDP)."""
+        st = getattr(self, "_flat_dense", None)
+        return list(st["params"]) if st is not None else []
+
+    def finish_dense_grads(self) -> None:
+        """Waits for the flat-buffer all-reduces of this step and attaches the slices as `.grad`."""
+        st = getattr(self, "_flat_dense", None)
+        if st is None:
+            return
+        for w in st["works"]:
+            w.wait()
+        st["works"].clear()
+        for q, v in zip(st["params"], st["views"]):
+            q.grad = v
 
     def forward(self, batch) -> Tuple[torch.Tensor, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
         g = self._graphs
