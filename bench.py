@@ -203,7 +203,9 @@ def main():
             avg_ms = tot_ms / max(args.steps, 1)  # per step (one launch per step at N = 1)
             kern[name] = {"avg_us": avg_ms * 1e3, "launches": n, "algorithmic_MB": nbytes / 1e6,
                           "GB/s": nbytes / (avg_ms * 1e-3) / 1e9}
-    dom = max((k for k in kern if not k.startswith("tbe_backward_")), key=lambda k: kern[k]["avg_us"], default=None)
+    # the dominant KERNEL (slots 0 and 1 are single kernels; slots 2 and 3 are multi-kernel spans)
+    dom = max((k for k in kern if k in ("tbe_fwd_short_kernel", "bwd_update_kernel")),
+              key=lambda k: kern[k]["avg_us"], default=None)
     roofline = None
     if dom:
         # PMC traffic (FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction) measured by a separate rocprofv3
