@@ -63,6 +63,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--num-batches", type=int, default=16, help="distinct pre-generated batches")
+    ap.add_argument("--row-wise", type=int, default=0,
+                    help="force the N largest tables row-wise (BASELINE config 3's mixed table-wise + row-wise plan); "
+                         "default 0 = the planner's own choice, which shards row-wise only for capacity")
     ap.add_argument("--tuned-gemms", choices=["on", "off"], default="on",
                     help="replay the recorded hipBLASLt / rocBLAS kernel choice per GEMM shape (torchrec_amd/tuning)")
     ap.add_argument("--hip-graphs", choices=["auto", "on", "off"], default="auto",
@@ -118,9 +121,12 @@ def main():
                             dense_arch_layer_sizes=[512, 256, 128],
                             over_arch_layer_sizes=[1024, 1024, 512, 256, 1], dense_device=dev)
     hip_graphs = args.hip_graphs == "on" or (args.hip_graphs == "auto" and B_local <= 32768)
+    from torchrec_amd.distributed.planner import EmbeddingShardingPlanner, Topology
+
     model = DistributedModelParallel(
         module=train_model, env=env, device=dev,
         sharders=[EmbeddingBagCollectionSharder(fused_params={"learning_rate": args.lr})],
+        planner=EmbeddingShardingPlanner(Topology(env.world_size), num_row_wise=args.row_wise or None),
         init_data_parallel=False)
     if hip_graphs:
         # HIP-graph replay of the collective-free dense segments; captured before DistributedDataParallel
