@@ -29,6 +29,7 @@ from torch import nn
 from ..modules.embedding_configs import EmbeddingConfig
 from ..sparse.jagged_tensor import JaggedTensor, KeyedJaggedTensor
 from . import embeddingbag as _eb
+from .embedding_sharding import bucketize_kjt_before_all2all
 from .planner import rw_block_size, rw_shard_rows
 from .types import Awaitable, LazyAwaitable, NoWait, ParameterSharding, ShardingEnv, ShardingType
 
@@ -158,7 +159,8 @@ class ShardedEmbeddingCollection(nn.Module):
         lengths, values = sub.lengths(), sub.values()
         Frw = len(self._rw_feats)
         blocks = torch.tensor(self._rw_blocks, dtype=values.dtype, device=values.device)
-        nl, ni, _, _, unb = torch.ops.fbgemm.block_bucketize_sparse_features(lengths, values, False, True, blocks, W, None)
+        bucketized, unb = bucketize_kjt_before_all2all(sub, W, blocks, output_permute=True)
+        nl, ni = bucketized.lengths(), bucketized.values()
         if W > 1:
             val_in = nl.view(W, -1).sum(dim=1).cpu().tolist()  # host sync (dist_data.py:396-398)
             recv_l = torch.empty(W * Frw * B, dtype=nl.dtype, device=nl.device)
