@@ -191,11 +191,12 @@ class DLRMTrain(nn.Module):
         Steps with another batch size, eval mode or no_grad run eagerly as before.
 
         flat_grads: the backward graphs write the parameter gradients, already divided by the world
-        size, into ONE flat buffer; each segment's slice is all-reduced (asynchronously, as soon as its
-        backward replay is enqueued) over `process_group`, and `finish_dense_grads()` attaches the
-        slices as `.grad`.  This replaces DistributedDataParallel for these parameters (16 per-parameter
-        bucket copies + hook overhead per step — the per-rank step of an N > 1 run is host-bound);
-        DistributedModelParallel.init_data_parallel() keeps them out of DDP."""
+        size, into ONE flat buffer; the head's slice is all-reduced asynchronously as soon as its backward
+        replay is enqueued, the rest (bottom segment + the model's remaining dense parameters, i.e. the
+        replicated tiny tables) by `finish_dense_grads()`, which also attaches the slices as `.grad`.
+        This replaces DistributedDataParallel altogether (its forward wrapper alone cost 0.43 ms of host
+        time per step, plus 16 per-parameter bucket copies — the per-rank step of an N > 1 run is
+        host-bound); DistributedModelParallel.init_data_parallel() broadcasts rank 0's values instead."""
         from ..distributed.hip_graph import GraphedSegment
 
         m = self.model
@@ -217,9 +218,14 @@ class DLRMTrain(nn.Module):
 
             world = dist.get_world_size(process_group) if process_group is not None else 1
             scale = 1.0 / world
+            graphed = {id(q) for q in list(g_head._params) + list(g_dense._params)}
+            # every other trainable dense parameter of the model (the replicated tiny tables of a sharded
+            # collection): its gradient arrives through autograd and joins the flat buffer after backward
+            extras = [q for q in self.parameters() if q.requires_grad and id(q) not in graphed]
             n_head = sum(q.numel() for q in g_head._params)
             n_dense = sum(q.numel() for q in g_dense._params)
-            flat = torch.zeros(n_head + n_dense, dtype=torch.float32, device=dev)
+            n_extra = sum(q.numel() for q in extras)
+            flat = torch.zeros(n_head + n_dense + n_extra, dtype=torch.float32, device=dev)
 
             def views(params, off):
                 out = []
@@ -229,17 +235,16 @@ class DLRMTrain(nn.Module):
                 return out
 
             head_sinks, dense_sinks = views(g_head._params, 0), views(g_dense._params, n_head)
-            state = {"flat": flat, "params": list(g_head._params) + list(g_dense._params),
-                     "views": head_sinks + dense_sinks, "works": [], "pg": process_group, "world": world}
+            extra_views = views(extras, n_head + n_dense)
+            state = {"flat": flat, "params": list(g_head._params) + list(g_dense._params) + extras,
+                     "views": head_sinks + dense_sinks + extra_views, "extras": list(zip(extras, extra_views)),
+                     "n_head": n_head, "works": [], "pg": process_group, "world": world, "scale": scale}
 
-            def reducer(lo, hi):
-                def start():
-                    if state["world"] > 1:
-                        state["works"].append(dist.all_reduce(flat[lo:hi], group=state["pg"], async_op=True))
-                return start
+            def reduce_head():  # the head's backward runs first: its slice overlaps the rest of backward
+                if state["world"] > 1:
+                    state["works"].append(dist.all_reduce(flat[:n_head], group=state["pg"], async_op=True))
 
-            g_head.after_backward = reducer(0, n_head)            # the head's backward runs first
-            g_dense.after_backward = reducer(n_head, n_head + n_dense)
+            g_head.after_backward = reduce_head
             object.__setattr__(self, "_flat_dense", state)
         g_head.capture_backward(param_grad_sinks=head_sinks, sink_scale=scale)
         # the head's gradient w.r.t. the bottom-MLP output doubles as the bottom segment's grad_output buffer
@@ -252,10 +257,23 @@ class DLRMTrain(nn.Module):
         return list(st["params"]) if st is not None else []
 
     def finish_dense_grads(self) -> None:
-        """Waits for the flat-buffer all-reduces of this step and attaches the slices as `.grad`."""
+        """After backward: folds the autograd gradients of the non-graphed dense parameters into the flat
+        buffer, all-reduces the rest of it (bottom segment + those), waits, and attaches the slices as
+        `.grad` (every rank then holds the rank-averaged gradient, as under DistributedDataParallel)."""
         st = getattr(self, "_flat_dense", None)
         if st is None:
             return
+        for q, v in st["extras"]:
+            if q.grad is None:
+                v.zero_()
+            elif q.grad.data_ptr() != v.data_ptr():
+                torch.mul(q.grad, st["scale"], out=v)
+            elif st["scale"] != 1.0:
+                v.mul_(st["scale"])  # autograd accumulated in place (zero_grad(set_to_none=False))
+        if st["world"] > 1:
+            import torch.distributed as dist
+
+            st["works"].append(dist.all_reduce(st["flat"][st["n_head"]:], group=st["pg"], async_op=True))
         for w in st["works"]:
             w.wait()
         st["works"].clear()
