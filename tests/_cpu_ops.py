@@ -54,6 +54,11 @@ def _x_unpack(recv, feat_out_col, feat_src, feat_slab_col, slab_offset, slab_str
                                                    B_local, False, scale))
 
 
+def _x_unpack_into(recv, feat_out_col, feat_src, feat_slab_col, slab_offset, slab_stride, B_local, D_total, vec, scale, out):
+    out.copy_(_x_unpack(recv, feat_out_col, feat_src, feat_slab_col, slab_offset, slab_stride, B_local, D_total, vec, scale))
+    return out
+
+
 def _x_pack(grad, feat_out_col, feat_src, feat_slab_col, slab_offset, slab_stride, numel, vec, scale):
     return torch.from_numpy(oracle.pooled_exchange(grad.contiguous().numpy(), feat_out_col.numpy(), feat_src.numpy(),
                                                    feat_slab_col.numpy(), slab_offset.numpy(), slab_stride.numpy(),
@@ -80,6 +85,7 @@ def register() -> None:
     _lib.impl("offsets_range", _offsets_range)
     _lib.impl("jagged_2d_to_dense", _jagged_2d_to_dense)
     _lib2.impl("pooled_exchange_unpack", _x_unpack)
+    _lib2.impl("pooled_exchange_unpack_into", _x_unpack_into)
     _lib2.impl("pooled_exchange_pack", _x_pack)
     _lib2.impl("a2a_pooled_unpack", _s_unpack)
     _lib2.impl("a2a_pooled_pack", _s_pack)

@@ -9,6 +9,8 @@ from fbgemm_gpu._lib import check, ptr, require_gpu, stream_ptr
 _def = torch.library.Library("tbe_hip", "DEF")
 _def.define("pooled_exchange_unpack(Tensor recv, Tensor feat_out_col, Tensor feat_src, Tensor feat_slab_col, "
             "Tensor slab_offset, Tensor slab_stride, int B_local, int D_total, bool vec, float scale) -> Tensor")
+_def.define("pooled_exchange_unpack_into(Tensor recv, Tensor feat_out_col, Tensor feat_src, Tensor feat_slab_col, "
+            "Tensor slab_offset, Tensor slab_stride, int B_local, int D_total, bool vec, float scale, Tensor(a!) out) -> Tensor(a!)")
 _def.define("pooled_exchange_pack(Tensor grad, Tensor feat_out_col, Tensor feat_src, Tensor feat_slab_col, "
             "Tensor slab_offset, Tensor slab_stride, int numel, bool vec, float scale) -> Tensor")
 _def.define("a2a_pooled_unpack(Tensor recv, Tensor dim_sum_per_rank, int B_local, int D_total, bool vec, float scale) -> Tensor")
@@ -57,9 +59,17 @@ def _simple_pack(grad, dims, vec, scale):
 
 
 def _unpack(recv, feat_out_col, feat_src, feat_slab_col, slab_offset, slab_stride, B_local, D_total, vec, scale):
-    dev = require_gpu(recv, feat_out_col, feat_src, feat_slab_col, slab_offset, slab_stride)
+    out = torch.empty((B_local, D_total), dtype=torch.float32, device=recv.device)
+    return _unpack_into(recv, feat_out_col, feat_src, feat_slab_col, slab_offset, slab_stride, B_local, D_total, vec,
+                        scale, out)
+
+
+def _unpack_into(recv, feat_out_col, feat_src, feat_slab_col, slab_offset, slab_stride, B_local, D_total, vec, scale, out):
+    """Same, into a caller-provided [B_local, D_total] buffer (e.g. the static input of a HIP-graph segment)."""
+    dev = require_gpu(recv, feat_out_col, feat_src, feat_slab_col, slab_offset, slab_stride, out)
     recv = recv.contiguous()
-    out = torch.empty((B_local, D_total), dtype=torch.float32, device=dev)
+    if out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != B_local * D_total:
+        raise RuntimeError("pooled_exchange_unpack_into: out must be a contiguous float32 [B_local, D_total] buffer")
     with torch.cuda.device(dev):
         check(_lib.load().tbe_pooled_exchange_unpack(
             ptr(recv), ptr(out), ptr(feat_out_col), ptr(feat_src), ptr(feat_slab_col), ptr(slab_offset),
@@ -83,6 +93,7 @@ def _pack(grad, feat_out_col, feat_src, feat_slab_col, slab_offset, slab_stride,
 
 _impl.impl("relu_backward_bias_grad", _relu_backward_bias_grad)
 _impl.impl("pooled_exchange_unpack", _unpack)
+_impl.impl("pooled_exchange_unpack_into", _unpack_into)
 _impl.impl("pooled_exchange_pack", _pack)
 _impl.impl("a2a_pooled_unpack", _simple_unpack)
 _impl.impl("a2a_pooled_pack", _simple_pack)

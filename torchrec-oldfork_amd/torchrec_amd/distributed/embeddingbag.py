@@ -149,6 +149,12 @@ class _ExchangeState:
         self.work.wait()
         self.work = None
         lay = self.lay
+        buf = self.o._output_buffer
+        if buf is not None and buf.numel() == self.B * self.o._D_total:
+            # the consumer's own buffer (e.g. the static input of a HIP-graph segment): no copy downstream
+            return torch.ops.tbe_hip.pooled_exchange_unpack_into(
+                self.recv_fwd, lay["feat_out_col"], lay["feat_src"], lay["feat_slab_col"], lay["slab_offset"],
+                lay["slab_stride"], self.B, self.o._D_total, self.o._vec_ok, 1.0, self.o._alias_output_buffer(self.B))
         return torch.ops.tbe_hip.pooled_exchange_unpack(
             self.recv_fwd, lay["feat_out_col"], lay["feat_src"], lay["feat_slab_col"], lay["slab_offset"],
             lay["slab_stride"], self.B, self.o._D_total, self.o._vec_ok, 1.0)
@@ -294,6 +300,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
         self._vec_ok = all(d % 4 == 0 for d in g_dim)
         self._layout_cache: Dict[int, Dict[str, Any]] = {}
         self._kjt_cache: Dict[Tuple, Any] = {}
+        self._output_buffer: Optional[torch.Tensor] = None  # see set_output_buffer
         # ---- local tables + TBE ----------------------------------------------------------------
         self._local_tables: List[_LocalTable] = []
         local_table_index: Dict[int, int] = {}
@@ -343,6 +350,21 @@ class ShardedEmbeddingBagCollection(nn.Module):
             for t, w in zip(self._dp_table_ids, self._dp_module.split_embedding_weights()):
                 w.uniform_(cfgs[t].get_weight_init_min(), cfgs[t].get_weight_init_max())
             self._dp_out_off = torch.tensor([out_col[g] for g in self._dp_feats], dtype=torch.int64, device=dev)
+
+    def set_output_buffer(self, buf: Optional[torch.Tensor]) -> None:
+        """A persistent float32 buffer of B_local * sum(D) elements that receives the pooled output of every
+        step with that batch size (instead of a fresh allocation) — e.g. the static input of a HIP-graph
+        segment, so that the segment reads the embeddings in place.  The caller owns the aliasing: the
+        output of step i is overwritten by step i + 1."""
+        self._output_buffer = buf
+
+    def _alias_output_buffer(self, B: int) -> torch.Tensor:
+        """A fresh [B, sum D] tensor over the output buffer's storage that is NOT an autograd view of it
+        (later lookups write their column blocks into it in place, which autograd forbids for views
+        created inside a custom Function)."""
+        buf = self._output_buffer
+        return torch.empty(0, dtype=torch.float32, device=buf.device).set_(
+            buf.untyped_storage(), buf.storage_offset(), (B, self._D_total), (self._D_total, 1))
 
     # ---- parameters -----------------------------------------------------------------------------
     def _init_parameters(self) -> None:
@@ -544,11 +566,14 @@ class ShardedEmbeddingBagCollection(nn.Module):
         B = dist_input.batch_size
         keys, lpe = self._feature_names, self._lengths_per_embedding
         if not self._exchange:
-            if self._dp_module is None:
+            buf = self._output_buffer
+            use_buf = buf is not None and buf.numel() == B * self._D_total
+            if self._dp_module is None and not use_buf:
                 emb = self._emb_module(dist_input.values, dist_input.offsets, dist_input.weights)
                 return NoWait(KeyedTensor(keys, lpe, emb))
             # both lookups write their column blocks of ONE [B, sum D] matrix
-            out = torch.empty((B, self._D_total), dtype=torch.float32, device=self._device)
+            out = (self._alias_output_buffer(B) if use_buf
+                   else torch.empty((B, self._D_total), dtype=torch.float32, device=self._device))
             if self._emb_module is not None:
                 out = self._emb_module.forward_into(out, self._sharded_out_off, self._D_total, dist_input.values,
                                                     dist_input.offsets, dist_input.weights)

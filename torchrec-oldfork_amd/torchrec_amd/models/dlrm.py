@@ -246,6 +246,11 @@ class DLRMTrain(nn.Module):
 
             g_head.after_backward = reduce_head
             object.__setattr__(self, "_flat_dense", state)
+        # the embedding collection writes its pooled output straight into the head segment's static input
+        ebc = m.sparse_arch.embedding_bag_collection
+        ebc = getattr(ebc, "sharded", ebc)  # a train pipeline may have wrapped it
+        if hasattr(ebc, "set_output_buffer"):
+            ebc.set_output_buffer(g_head.static_input(1).detach())
         g_head.capture_backward(param_grad_sinks=head_sinks, sink_scale=scale)
         # the head's gradient w.r.t. the bottom-MLP output doubles as the bottom segment's grad_output buffer
         g_dense.capture_backward([g_head.static_grad_inputs[0]], param_grad_sinks=dense_sinks, sink_scale=scale)
