@@ -352,6 +352,13 @@ int tbe_relu_backward_bias_grad_f32(const float* grad_out, const float* act, int
                                     float* grad_in, float* bias_grad, void* workspace,
                                     size_t workspace_bytes, void* stream);
 
+/* Weight gradient of a Linear with ONE output feature (DLRM's last layer, torchrec/models/dlrm.py OverArch:
+ * `nn.Linear(layer_sizes[-2], 1)`): out[c] = sum_b w[b] * x[b, c] for x [B, N] row-major, w [B] — the
+ * N = 1 GEMM the BLAS libraries run at ~1 % of HBM speed.  N a multiple of 4; fixed summation order. */
+size_t tbe_weighted_colsum_workspace_bytes(int64_t B, int32_t N);
+int tbe_weighted_colsum_f32(const float* x, const float* w, int64_t B, int32_t N, float* out,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
 /* torch.ops.fbgemm.jagged_2d_to_dense (examples/bert4rec/models/bert4rec.py:394-400):
  * values [N, D] + offsets [B+1] -> dense [B, max_L, D], zero padded / truncated. */
 int tbe_jagged_2d_to_dense_f32(const float* values, const int64_t* offsets, int32_t B,

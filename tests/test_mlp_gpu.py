@@ -83,3 +83,28 @@ def test_tuned_gemm_replay_keeps_results():
     finally:
         tunable.enable(False)
     assert max(base) < 1e-4 and max(tuned) < 1e-4, (base, tuned)
+
+
+@pytest.mark.parametrize("B,N", [(65536, 256), (8192, 256), (1000, 52), (5, 8)])
+def test_weighted_colsum_and_one_output_linear(B, N):
+    """csrc/mlp_epilogue.hip wcolsum: dW of a one-output Linear in one pass; the LinearOut module equals nn.Linear."""
+    import torchrec_amd.distributed._device_ops  # noqa: F401
+    from torchrec_amd.modules.mlp import LinearOut
+
+    torch.manual_seed(2)
+    x = torch.randn(B, N, device="cuda")
+    w = torch.randn(B, device="cuda")
+    out = torch.ops.tbe_hip.weighted_colsum(x, w)
+    ref = (x.double() * w.double()[:, None]).sum(0)
+    assert float((out.double() - ref).abs().max() / ref.abs().mean()) < 1e-4
+    assert torch.equal(out, torch.ops.tbe_hip.weighted_colsum(x, w))  # fixed order: bitwise reproducible
+    lin = LinearOut(N, 1, device=torch.device("cuda"))
+    ref_lin = torch.nn.Linear(N, 1, device=torch.device("cuda"))
+    ref_lin.load_state_dict(lin.state_dict())
+    xi, xr = x.clone().requires_grad_(), x.clone().requires_grad_()
+    g = torch.randn(B, 1, device="cuda")
+    lin(xi).backward(g)
+    ref_lin(xr).backward(g)
+    torch.testing.assert_close(xi.grad, xr.grad, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(lin.weight.grad, ref_lin.weight.grad, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(lin.bias.grad, ref_lin.bias.grad, rtol=1e-4, atol=1e-3)

@@ -127,6 +127,9 @@ SIGNATURES = {
     "tbe_relu_backward_bias_grad_workspace_bytes": (c_size, [c_i64, c_i32]),
     "tbe_relu_backward_bias_grad_f32": (
         ctypes.c_int, [c_void_p, c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
+    "tbe_weighted_colsum_workspace_bytes": (c_size, [c_i64, c_i32]),
+    "tbe_weighted_colsum_f32": (
+        ctypes.c_int, [c_void_p, c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_size, c_void_p]),
     "tbe_jagged_2d_to_dense_f32": (
         ctypes.c_int, [c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p, c_void_p]),
     "tbe_dense_to_jagged_2d_f32": (

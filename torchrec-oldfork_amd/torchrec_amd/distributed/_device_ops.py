@@ -16,7 +16,24 @@ _def.define("pooled_exchange_pack(Tensor grad, Tensor feat_out_col, Tensor feat_
 _def.define("a2a_pooled_unpack(Tensor recv, Tensor dim_sum_per_rank, int B_local, int D_total, bool vec, float scale) -> Tensor")
 _def.define("a2a_pooled_pack(Tensor grad, Tensor dim_sum_per_rank, bool vec, float scale) -> Tensor")
 _def.define("relu_backward_bias_grad(Tensor grad_out, Tensor act) -> (Tensor, Tensor)")
+_def.define("weighted_colsum(Tensor x, Tensor w) -> Tensor")
 _impl = torch.library.Library("tbe_hip", "IMPL", "CUDA")
+
+
+def _weighted_colsum(x, w):
+    """out[c] = sum_b w[b] * x[b, c] (csrc/mlp_epilogue.hip)."""
+    from fbgemm_gpu._lib import workspace
+
+    dev = require_gpu(x, w)
+    x, w = x.contiguous(), w.contiguous().view(-1)
+    B, N = x.shape
+    out = torch.empty(N, dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        ws = workspace(lib.tbe_weighted_colsum_workspace_bytes(B, N), dev)
+        check(lib.tbe_weighted_colsum_f32(ptr(x), ptr(w), B, N, ptr(out), ptr(ws), ws.numel(), stream_ptr(dev)),
+              "tbe_weighted_colsum_f32")
+    return out
 
 
 def _relu_backward_bias_grad(grad_out, act):
@@ -92,6 +109,7 @@ def _pack(grad, feat_out_col, feat_src, feat_slab_col, slab_offset, slab_stride,
 
 
 _impl.impl("relu_backward_bias_grad", _relu_backward_bias_grad)
+_impl.impl("weighted_colsum", _weighted_colsum)
 _impl.impl("pooled_exchange_unpack", _unpack)
 _impl.impl("pooled_exchange_unpack_into", _unpack_into)
 _impl.impl("pooled_exchange_pack", _pack)

@@ -8,7 +8,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 from torch import nn
 
-from ..modules.mlp import MLP
+from ..modules.mlp import MLP, LinearOut
 from ..sparse.jagged_tensor import KeyedJaggedTensor, KeyedTensor
 
 
@@ -122,7 +122,7 @@ class OverArch(nn.Module):
             raise ValueError("OverArch must have multiple layers.")
         self.model = nn.Sequential(
             MLP(in_features, layer_sizes[:-1], bias=True, activation="relu", device=device),
-            nn.Linear(layer_sizes[-2], layer_sizes[-1], bias=True, device=device))
+            LinearOut(layer_sizes[-2], layer_sizes[-1], bias=True, device=device))
 
     def forward(self, features: torch.Tensor) -> torch.Tensor:
         return self.model(features)
