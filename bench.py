@@ -133,8 +133,19 @@ def main():
         # wraps the dense modules (distributed/train_pipeline.py explains why)
         # With a process group the segments' gradients travel through ONE flat buffer that is all-reduced
         # per segment, instead of DDP's per-parameter bucket copies (models/dlrm.py)
-        train_model.capture_hip_graphs(B_local, flat_grads=env.process_group is not None,
-                                       process_group=env.process_group)
+        try:
+            train_model.capture_hip_graphs(B_local, flat_grads=env.process_group is not None,
+                                           process_group=env.process_group)
+        except Exception as e:  # measured run must not die on a capture problem: run the segments eagerly
+            print(f"[bench] HIP-graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr, flush=True)
+            train_model._graphs = None
+            if hasattr(train_model, "_flat_dense"):
+                object.__delattr__(train_model, "_flat_dense")
+            ebc_now = train_model.model.sparse_arch.embedding_bag_collection
+            if hasattr(ebc_now, "set_output_buffer"):
+                ebc_now.set_output_buffer(None)
+            torch.cuda.synchronize()
+            hip_graphs = False
     model.init_data_parallel()
     dense_params = dict(model.named_parameters())
     optimizer = CombinedOptimizer([
