@@ -356,14 +356,15 @@ def _check_seq(ret, W, D=4):
         pos = np.concatenate([[0], np.cumsum([lengths[f * B:(f + 1) * B].sum() for f in range(3)])])
         for f, k in enumerate(keys):
             np.testing.assert_array_equal(embs[k], init[f][vals[pos[f]:pos[f + 1]]])
-    # backward: global batch = concat over ranks per feature, grads / W, exact SGD
+    # backward: global batch = concat over ranks per feature, exact SGD (the reference does not divide the
+    # sequence gradient by the world size, unlike the pooled path)
     g_vals, g_grad, g_len = [], [], []
     for f in range(3):
         for r in range(W):
             embs, lengths, vals, g, _ = ret[r]
             pos = np.concatenate([[0], np.cumsum([lengths[ff * B:(ff + 1) * B].sum() for ff in range(3)])])
             g_vals.append(vals[pos[f]:pos[f + 1]])
-            g_grad.append(g[pos[f]:pos[f + 1]] / W)
+            g_grad.append(g[pos[f]:pos[f + 1]])  # no 1/W on the sequence path (comm_ops.py:718-749)
             g_len.append(lengths[f * B:(f + 1) * B])
     g_vals, g_grad, g_len = np.concatenate(g_vals), np.concatenate(g_grad), np.concatenate(g_len)
     offs = np.concatenate([[0], np.cumsum(g_len)]).astype(np.int64)

@@ -12,7 +12,11 @@ Data path per step (W ranks, rank r owns the features of its tables):
            rank sent — i.e. already grouped [feature][sample] per destination, from which the
            per-feature JaggedTensors are sliced without a copy when features are sent in
            collection order;
-  grads  : the same all-to-all reversed (x 1/W, comm_ops.py:704-706), then the fused TBE backward.
+  grads  : the same all-to-all reversed, then the fused TBE backward.  As in the reference, the gradient is
+           NOT divided by the world size on this path: GRADIENT_DIVISION only acts on the pooled all-to-all
+           (comm_ops.py:527-528) and the reduce-scatter (:883-885); All2All_Seq_Req_Wait.backward
+           (comm_ops.py:718-749) sends the gradient as is.  `SEQUENCE_GRADIENT_DIVISION = True` opts into
+           the pooled path's convention (sharded == unsharded for a mean loss).
 
 Row-wise tables (sharding/rw_sequence_sharding.py): ids are bucketized by row block with
 `fbgemm.block_bucketize_sparse_features(sequence=True)` (embedding_sharding.py:121-184), bucket r goes
@@ -28,10 +32,12 @@ from torch import nn
 
 from ..modules.embedding_configs import EmbeddingConfig
 from ..sparse.jagged_tensor import JaggedTensor, KeyedJaggedTensor
-from . import embeddingbag as _eb
 from .embedding_sharding import bucketize_kjt_before_all2all
 from .planner import rw_block_size, rw_shard_rows
 from .types import Awaitable, LazyAwaitable, NoWait, ParameterSharding, ShardingEnv, ShardingType
+
+
+SEQUENCE_GRADIENT_DIVISION = False  # reference behaviour (see the module docstring)
 
 
 def _default_seq_tbe_factory(specs, ftm, device, fused_params):
@@ -44,7 +50,7 @@ def _default_seq_tbe_factory(specs, ftm, device, fused_params):
 
 
 class _SeqExchange(torch.autograd.Function):
-    """rows [sum(send_counts), D] -> rows [sum(recv_counts), D]; backward is the reverse exchange / W."""
+    """rows [sum(send_counts), D] -> rows [sum(recv_counts), D]; backward is the reverse exchange."""
 
     @staticmethod
     def forward(ctx, emb, pg, send_counts, recv_counts):
@@ -59,7 +65,7 @@ class _SeqExchange(torch.autograd.Function):
         D = grad.shape[1]
         W = dist.get_world_size(ctx.pg)
         g = grad.contiguous()
-        if _eb.GRADIENT_DIVISION:
+        if SEQUENCE_GRADIENT_DIVISION:
             g = g / W
         out = torch.empty((sum(ctx.send_counts), D), dtype=g.dtype, device=g.device)
         dist.all_to_all_single(out, g, list(ctx.send_counts), list(ctx.recv_counts), group=ctx.pg)
