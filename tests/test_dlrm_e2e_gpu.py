@@ -91,7 +91,7 @@ def test_dlrm_training_matches_plain_torch_reference():
     it = iter(batches)
     bce = nn.BCEWithLogitsLoss()
     for step in range(6):
-        loss, _ = pipe.progress(it)
+        loss = pipe.progress(it)[0]  # DLRMTrain output = (loss.detach(), logits, labels)
         b = batches[step]
         ref_opt.zero_grad()
         ref_loss = bce(ref(b.dense_features, b.sparse_features.values(), B), b.labels.float())

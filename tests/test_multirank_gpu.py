@@ -330,7 +330,7 @@ def _e2e_run(model, opt, keys, batches, rank, W, dev, hip_graphs=False):
     it = iter(bl)
     losses = []
     for _ in range(E_STEPS):
-        loss, _ = pipe.progress(it)
+        loss = pipe.progress(it)[0]
         losses.append(float(loss.detach()))
     torch.cuda.synchronize()
     s = model.sharded_modules()[0]

@@ -255,7 +255,7 @@ def _e2e_worker(rank, W, port, ret):
         it = iter(data)
         losses = []
         for _ in range(4):
-            loss, _ = pipe.progress(it)
+            loss = pipe.progress(it)[0]
             losses.append(float(loss))
         dense_sd = {k: v.detach().clone() for k, v in model.named_parameters()}
         shards = {n: (w.clone().numpy(), r0) for n, (w, r0) in model.sharded_modules()[0].local_shards().items()}
