@@ -51,6 +51,24 @@ BYTES_FWD = F * (D * 4 + 8) + F * 8 + F * D * 4          # 27 040
 BYTES_BWD_SGD = F * D * 4 + F * 16 + 2 * F * D * 4       # 40 352
 
 
+import contextlib  # noqa: E402
+
+
+@contextlib.contextmanager
+def native_stdout_to_stderr():
+    """RCCL prints a version banner on the C-level stdout when a communicator is created; the contract is ONE
+    JSON line on stdout, so file descriptor 1 points at stderr while the process group comes up."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -97,10 +115,12 @@ def main():
     if world > 1 or rehearse:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        if rehearse:
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+        with native_stdout_to_stderr():
+            if rehearse:
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            else:
+                dist.init_process_group("nccl", device_id=dev)
+            dist.barrier()  # the communicator (and its banner) exists before stdout is handed back
         env = ShardingEnv.from_process_group(dist.group.WORLD)
     else:
         env = ShardingEnv.from_local(1, 0)
