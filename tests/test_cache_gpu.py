@@ -170,3 +170,34 @@ def test_unpooled_lookup_through_the_cache():
         b.backward(g)
     for x, y in zip(cached.split_embedding_weights(), plain.split_embedding_weights()):
         torch.testing.assert_close(x.cpu(), y.cpu(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_cache_stress_random_shapes(seed):
+    """Many steps with random batch sizes / pooling factors / id skew over tiny caches: every step's output and
+    the final tables must track the uncached module (exercises the lock-free way claiming, eviction write-back,
+    staging growth and re-insertion of evicted rows under heavy set conflicts)."""
+    from fbgemm_gpu.split_embedding_configs import EmbOptimType
+    from fbgemm_gpu.split_table_batched_embeddings_ops import EmbeddingLocation as L
+
+    rng = np.random.default_rng(100 + seed)
+    rows, dims = [int(rng.integers(200, 20000)), int(rng.integers(50, 5000))], [64, 64]
+    sets = int(rng.choice([1, 2, 5]))
+    opt = [EmbOptimType.EXACT_SGD, EmbOptimType.EXACT_ROWWISE_ADAGRAD][seed % 2]
+    cached, plain = _modules(rows, dims, [L.MANAGED_CACHING, L.MANAGED_CACHING], opt, cache_sets=sets)
+    for t in range(2):
+        init = rng.standard_normal((rows[t], dims[t])).astype(np.float32)
+        cached.split_embedding_weights()[t].copy_(torch.from_numpy(init))
+        plain.split_embedding_weights()[t].copy_(torch.from_numpy(init))
+    for step in range(25):
+        B = int(rng.integers(1, 400))
+        indices, offsets, _ = make_inputs(rng, rows, B, int(rng.integers(1, 5)), zipf=bool(step % 3))
+        a, b = cached(to_dev(indices), to_dev(offsets)), plain(to_dev(indices), to_dev(offsets))
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5, msg=lambda m: f"step {step}: {m}")
+        g = to_dev(rng.standard_normal(tuple(a.shape)).astype(np.float32))
+        a.backward(g)
+        b.backward(g)
+    st = cached.cache_stats()
+    assert st["evictions"] > 0 and st["hits"] > 0
+    for x, y in zip(cached.split_embedding_weights(), plain.split_embedding_weights()):
+        torch.testing.assert_close(x.cpu(), y.cpu(), rtol=1e-4, atol=1e-5)
