@@ -39,6 +39,16 @@ def _train(hip_graphs: bool, steps: int = 6, flat: bool = False):
     model.train()
     it = iter(data)
     losses = [float(pipe.progress(it)[0].detach()) for _ in range(steps)]
+    # one more step with ANOTHER batch size: graphed models must fall back to the eager segments (and, in
+    # flat-gradient mode, still deliver the gradients through the flat buffer)
+    small = RandomRecDataset(keys, B // 2, rows, manual_seed=9, num_generated_batches=1, num_batches=1, device=dev)
+    pipe._requests.clear()  # drop the queued input_dist of the next (full-size) batch: this step is manual
+    opt.zero_grad()
+    loss, _ = model(next(iter(small)))
+    loss.backward()
+    tm.finish_dense_grads()
+    opt.step()
+    losses.append(float(loss.detach()))
     torch.cuda.synchronize()
     assert (model.module._graphs is not None) == hip_graphs
     params = {k: v.detach().cpu().numpy().copy() for k, v in model.named_parameters()}

@@ -94,3 +94,16 @@ def test_hip_interaction_bit_exact_vs_oracle(B, F, D):
     ref.backward(torch.from_numpy(go).cuda())
     torch.testing.assert_close(td.grad, td2.grad, rtol=1e-5, atol=1e-4)
     torch.testing.assert_close(ts.grad, ts2.grad, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_interaction_refuses_mismatched_batches_before_launch():
+    """Shapes are checked on the host: a kernel launched with mismatched operands would read out of bounds."""
+    import torch
+
+    from torchrec_amd.models.dlrm import _FusedDotInteraction
+
+    dense = torch.randn(8, 128, device="cuda")
+    sparse = torch.randn(16, 26, 128, device="cuda")
+    with pytest.raises(RuntimeError, match="does not match"):
+        _FusedDotInteraction.apply(dense, sparse)

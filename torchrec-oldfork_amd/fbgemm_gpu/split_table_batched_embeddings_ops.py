@@ -527,6 +527,10 @@ class _TBEBase(nn.Module):
                 # caller-provided buffer + addressing (feat_out_offset, row stride): several lookups
                 # can fill disjoint column blocks of one [B, sum D] matrix without a cat
                 out, out_off, stride = into
+                if (out.dtype != torch.float32 or not out.is_contiguous() or out.device != dev
+                        or out.numel() < B * stride or out_off.numel() != self.F):
+                    raise RuntimeError("forward_into: `out` must be a contiguous float32 buffer of at least "
+                                       f"B * row_stride = {B * stride} elements on {dev}, with one offset per feature")
             else:
                 out_off, stride, shape = self._pooled_layout(B)
                 out = torch.empty(shape, dtype=torch.float32, device=dev)

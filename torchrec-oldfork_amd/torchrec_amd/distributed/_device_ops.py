@@ -25,6 +25,8 @@ def _weighted_colsum(x, w):
     from fbgemm_gpu._lib import workspace
 
     dev = require_gpu(x, w)
+    if x.dim() != 2 or w.numel() != x.shape[0] or x.dtype != torch.float32 or w.dtype != torch.float32:
+        raise RuntimeError(f"weighted_colsum: need float32 x [B, N] and w [B], got {tuple(x.shape)} and {tuple(w.shape)}")
     x, w = x.contiguous(), w.contiguous().view(-1)
     B, N = x.shape
     out = torch.empty(N, dtype=torch.float32, device=dev)
@@ -41,6 +43,9 @@ def _relu_backward_bias_grad(grad_out, act):
     from fbgemm_gpu._lib import workspace
 
     dev = require_gpu(grad_out, act)
+    if grad_out.dim() != 2 or grad_out.shape != act.shape or grad_out.dtype != torch.float32 or act.dtype != torch.float32:
+        raise RuntimeError(f"relu_backward_bias_grad: need two float32 [B, N] tensors of one shape, got "
+                           f"{tuple(grad_out.shape)} and {tuple(act.shape)}")
     grad_out, act = grad_out.contiguous(), act.contiguous()
     B, N = grad_out.shape
     gx = torch.empty_like(grad_out)

@@ -64,6 +64,9 @@ class _FusedDotInteraction(torch.autograd.Function):
 
         dense, sparse = dense.contiguous(), sparse.contiguous()
         B, F, D = sparse.shape
+        if dense.shape != (B, D) or sparse.device != dense.device:
+            raise RuntimeError(f"dot interaction: dense {tuple(dense.shape)} does not match sparse {tuple(sparse.shape)} "
+                               "(same batch, same embedding dim, same device required)")
         out = torch.empty((B, D + (F + 1) * F // 2), dtype=torch.float32, device=dense.device)
         with torch.cuda.device(dense.device):
             check(_lib.load().tbe_dlrm_interaction_forward_f32(ptr(dense), ptr(sparse), B, F, D, ptr(out),
@@ -80,6 +83,8 @@ class _FusedDotInteraction(torch.autograd.Function):
         dense, sparse = ctx.saved_tensors
         B, F, D = sparse.shape
         grad_out = grad_out.contiguous()
+        if grad_out.shape != (B, D + (F + 1) * F // 2):
+            raise RuntimeError(f"dot interaction backward: grad_out {tuple(grad_out.shape)} has the wrong shape")
         gd, gs = torch.empty_like(dense), torch.empty_like(sparse)
         with torch.cuda.device(dense.device):
             check(_lib.load().tbe_dlrm_interaction_backward_f32(ptr(dense), ptr(sparse), ptr(grad_out), B, F, D,
@@ -241,10 +246,16 @@ class DLRMTrain(nn.Module):
                      "n_head": n_head, "works": [], "pg": process_group, "world": world, "scale": scale}
 
             def reduce_head():  # the head's backward runs first: its slice overlaps the rest of backward
+                state["fired"] += 1
                 if state["world"] > 1:
                     state["works"].append(dist.all_reduce(flat[:n_head], group=state["pg"], async_op=True))
 
+            def dense_done():
+                state["fired"] += 1
+
+            state["fired"] = 0
             g_head.after_backward = reduce_head
+            g_dense.after_backward = dense_done
             object.__setattr__(self, "_flat_dense", state)
         # the embedding collection writes its pooled output straight into the head segment's static input
         ebc = m.sparse_arch.embedding_bag_collection
@@ -268,17 +279,35 @@ class DLRMTrain(nn.Module):
         st = getattr(self, "_flat_dense", None)
         if st is None:
             return
-        for q, v in st["extras"]:
-            if q.grad is None:
-                v.zero_()
-            elif q.grad.data_ptr() != v.data_ptr():
-                torch.mul(q.grad, st["scale"], out=v)
-            elif st["scale"] != 1.0:
-                v.mul_(st["scale"])  # autograd accumulated in place (zero_grad(set_to_none=False))
-        if st["world"] > 1:
-            import torch.distributed as dist
+        replayed = st["fired"] == 2
+        st["fired"] = 0
+        import torch.distributed as dist
 
-            st["works"].append(dist.all_reduce(st["flat"][st["n_head"]:], group=st["pg"], async_op=True))
+        if not replayed:
+            # this step ran eagerly (another batch size, ...): every gradient came through autograd; fold all of
+            # them into the flat buffer and reduce it as a whole
+            for w in st["works"]:
+                w.wait()
+            st["works"].clear()
+            for q, v in zip(st["params"], st["views"]):
+                if q.grad is None:
+                    v.zero_()
+                elif q.grad.data_ptr() != v.data_ptr():
+                    torch.mul(q.grad, st["scale"], out=v)
+                elif st["scale"] != 1.0:
+                    v.mul_(st["scale"])
+            if st["world"] > 1:
+                st["works"].append(dist.all_reduce(st["flat"], group=st["pg"], async_op=True))
+        else:
+            for q, v in st["extras"]:
+                if q.grad is None:
+                    v.zero_()
+                elif q.grad.data_ptr() != v.data_ptr():
+                    torch.mul(q.grad, st["scale"], out=v)
+                elif st["scale"] != 1.0:
+                    v.mul_(st["scale"])  # autograd accumulated in place (zero_grad(set_to_none=False))
+            if st["world"] > 1:
+                st["works"].append(dist.all_reduce(st["flat"][st["n_head"]:], group=st["pg"], async_op=True))
         for w in st["works"]:
             w.wait()
         st["works"].clear()
