@@ -107,7 +107,9 @@ int tbe_profile_read_rows(int64_t* rows_updated);
  * indices [N] int64, offsets [F*B+1] int64, per_sample_weights [N] float or NULL
  * out: float buffer addressed as above; out_row_stride in elements
  * bounds_errors  optional device int32 counter: incremented for every index outside
- *                [0, rows); such an index contributes a zero row (never dereferenced).
+ *                [0, rows); such an index contributes a zero row (never dereferenced).  Also incremented for
+ *                every bag whose offsets are malformed (start < 0, end > N, start > end): such a bag is
+ *                empty in forward and contributes nothing in backward — no memory is touched through it.
  * ---------------------------------------------------------------------------------- */
 int tbe_forward_pooled_f32(const uint64_t* feat_weights, const int32_t* feat_D,
                            const int64_t* feat_out_offset, const int64_t* feat_rows, int32_t F,

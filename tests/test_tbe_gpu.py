@@ -394,3 +394,57 @@ def test_sharded_ebc_world1_with_replicated_tables_writes_one_buffer():
         o = dpm.weights_offsets[i]
         np.testing.assert_allclose(flat[o:o + rows[t] * D].reshape(rows[t], D), gw[t], rtol=2e-5, atol=1e-4)
         np.testing.assert_array_equal(dpm.split_embedding_weights()[i].cpu().numpy(), init[t])
+
+
+def test_malformed_offsets_never_reach_memory():
+    """Offsets that run past the ids, go negative or backwards: such bags are empty and counted (forward and
+    backward), nothing is read or written through them, every well-formed bag is still exact."""
+    from fbgemm_gpu.split_embedding_configs import EmbOptimType
+
+    rng = np.random.default_rng(31)
+    rows, dims = [50, 20], [64, 64]
+    mod, tabs = build_pair(rows, dims, None, 0, optimizer=EmbOptimType.EXACT_SGD, rng=rng, learning_rate=0.5)
+    B = 8
+    indices, offsets, _ = make_inputs(rng, rows, B, 3)
+    N = indices.size
+    bad = offsets.copy()
+    bad[3] = -5          # bag 2 starts negative, bag 3 is fine again
+    bad[7] = N + 1000    # bag 6 runs far past the ids; bag 7 starts there (also malformed)
+    bad[12] = bad[11] - 1 if bad[11] > 0 else bad[11]  # goes backwards
+    before = mod.bounds_check_errors()
+    out = mod(to_dev(indices), to_dev(bad))
+    torch.cuda.synchronize()
+    assert mod.bounds_check_errors() > before
+    # expectation: the oracle on the same offsets with malformed bags emptied
+    good = np.zeros(2 * B, dtype=bool)
+    ref = np.zeros((B, 128), dtype=np.float32)
+    for bag in range(2 * B):
+        s, e = int(bad[bag]), int(bad[bag + 1])
+        if 0 <= s <= e <= N:
+            good[bag] = True
+            f, b = divmod(bag, B)
+            for p in range(s, e):
+                ref[b, f * 64:(f + 1) * 64] += tabs.weights[f][indices[p]]
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+    w_before = [w.clone() for w in mod.split_embedding_weights()]
+    g = rng.standard_normal((B, 128)).astype(np.float32)
+    out.backward(to_dev(g))
+    torch.cuda.synchronize()
+    exp = [w.cpu().numpy().copy() for w in w_before]
+    acc = [np.zeros_like(e_) for e_ in exp]
+    cover = np.zeros(N, dtype=np.int64)
+    for bag in range(2 * B):
+        if good[bag]:
+            cover[int(bad[bag]):int(bad[bag + 1])] += 1
+    ambiguous = [set(), set()]  # offsets that go backwards make bags overlap: which bag owns such an id is undefined
+    for bag in range(2 * B):
+        if good[bag]:
+            f, b = divmod(bag, B)
+            for p in range(int(bad[bag]), int(bad[bag + 1])):
+                if cover[p] > 1:
+                    ambiguous[f].add(int(indices[p]))
+                acc[f][indices[p]] += g[b, f * 64:(f + 1) * 64]
+    for t, w in enumerate(mod.split_embedding_weights()):
+        keep = np.array([r not in ambiguous[t] for r in range(rows[t])])
+        np.testing.assert_allclose(w.cpu().numpy()[keep], (exp[t] - 0.5 * acc[t])[keep], rtol=1e-5, atol=1e-5)
+        assert np.isfinite(w.cpu().numpy()).all()

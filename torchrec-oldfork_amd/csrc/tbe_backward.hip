@@ -70,13 +70,19 @@ template <typename KeyT>
 __global__ __launch_bounds__(256) void bwd_linearize_pooled_kernel(
     const int64_t* __restrict__ indices, const int64_t* __restrict__ offsets,
     const int64_t* __restrict__ feat_rows, const int64_t* __restrict__ feat_row_base, int F, int B,
-    int key_bits, KeyT* __restrict__ keys, uint64_t* __restrict__ payload,
+    int64_t N, int key_bits, KeyT* __restrict__ keys, uint64_t* __restrict__ payload,
     int32_t* bounds_errors) {
   const int64_t bag = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (bag >= static_cast<int64_t>(F) * B) return;
   const int f = static_cast<int>(bag / B);
   const int64_t s = offsets[bag];
   const int64_t e = offsets[bag + 1];
+  if (s < 0 || e > N || s > e) {
+    // malformed offsets: never touch memory through them.  The positions such a bag fails to cover keep the
+    // all-ones key the caller pre-filled, which the update kernel treats as "no row".
+    if (bounds_errors != nullptr) atomicAdd(bounds_errors, 1);
+    return;
+  }
   const int64_t rows = feat_rows[f];
   const int64_t base = feat_row_base[f];
   const KeyT sentinel = static_cast<KeyT>((key_bits >= 64) ? ~0ull : ((1ull << key_bits) - 1ull));
@@ -319,7 +325,7 @@ __global__ __launch_bounds__(256, MINW) void bwd_update_kernel(BwdArgs a) {
       pay_k = a.payload_sorted[kk];
       if (kk + 1 < a.N) keyn_k = skey[kk + 1];
     }
-    const bool valid_k = in && key_k != sentinel;
+    const bool valid_k = in && key_k < sentinel;  // sentinel = invalid id; anything above = never written
     const bool last_k = valid_k && (key_k != keyn_k || kk + 1 >= a.N);
     const uint32_t bag_k = static_cast<uint32_t>(pay_k >> 32);
     const uint32_t pos_k = static_cast<uint32_t>(pay_k);
@@ -710,8 +716,14 @@ static int run_backward(BwdArgs a, const BwdWorkspace& w, int32_t max_D, hipStre
   } else {
     const int64_t nbags = static_cast<int64_t>(a.F) * a.B;
     const unsigned grid = static_cast<unsigned>((nbags + 255) / 256);
+    // every key starts as all-ones (= invalid): positions that inconsistent offsets leave uncovered must not
+    // reach the update kernel as garbage rows
+    if (hipMemsetAsync(kin, 0xFF, static_cast<size_t>(a.N) * sizeof(KeyT), st) != hipSuccess) {
+      set_error("tbe_backward: hipMemsetAsync failed");
+      return TBE_ERR_LAUNCH;
+    }
     hipLaunchKernelGGL((bwd_linearize_pooled_kernel<KeyT>), dim3(grid), dim3(256), 0, st, a.indices,
-                       a.offsets, a.feat_rows, a.feat_row_base, a.F, a.B, a.key_bits, kin, w.pay_in,
+                       a.offsets, a.feat_rows, a.feat_row_base, a.F, a.B, a.N, a.key_bits, kin, w.pay_in,
                        a.bounds_errors);
   }
   TBE_CHECK_LAUNCH("tbe_backward linearize");

@@ -34,6 +34,7 @@ struct FwdArgs {
   float* out;
   int32_t* bounds_errors;
   int64_t out_stride;
+  int64_t N;  // number of ids: bag ranges outside [0, N] are treated as empty (and counted), never dereferenced
   int32_t F;
   int32_t B;
   int32_t bags_per_wave;  // 64, or 16 for small launches (more waves => more rows in flight)
@@ -99,6 +100,10 @@ __global__ __launch_bounds__(256) void tbe_fwd_short_kernel(FwdArgs a) {
   if (b_l < a.B && lane < bpw) {
     s_l = offs[b_l];
     e_l = offs[b_l + 1];
+    if (s_l < 0 || e_l > a.N || s_l > e_l) {  // malformed offsets: empty bag, counted, never dereferenced
+      s_l = e_l = 0;
+      if (a.bounds_errors != nullptr) atomicAdd(a.bounds_errors, 1);
+    }
   }
   const int len_l = static_cast<int>(e_l - s_l);
   int64_t idx0_l = 0;
@@ -225,8 +230,12 @@ __global__ __launch_bounds__(256) void tbe_fwd_long_kernel(FwdArgs a) {
   const bool vec = ((D & 3) == 0) && ((Doff & 3) == 0) && ((a.out_stride & 3) == 0) &&
                    ((reinterpret_cast<uintptr_t>(W) & 15) == 0) &&
                    ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0);
-  const int64_t s = a.offsets[bag];
-  const int64_t e = a.offsets[bag + 1];
+  int64_t s = a.offsets[bag];
+  int64_t e = a.offsets[bag + 1];
+  if (s < 0 || e > a.N || s > e) {  // malformed offsets: empty bag, counted, never dereferenced (wave-uniform)
+    s = e = 0;
+    if (a.bounds_errors != nullptr && lane == 0) atomicAdd(a.bounds_errors, 1);
+  }
   const int len = static_cast<int>(e - s);
   const int g = lane / G;
   const int gl = lane % G;
@@ -427,7 +436,7 @@ extern "C" int tbe_forward_pooled_f32(const uint64_t* feat_weights, const int32_
   TBE_REQUIRE(N == 0 || indices != nullptr, "tbe_forward_pooled_f32: null indices");
   hipStream_t st = static_cast<hipStream_t>(stream);
   FwdArgs a{feat_weights, feat_D, feat_out_offset, feat_rows, indices, offsets, per_sample_weights,
-            out, bounds_errors, out_row_stride, F, B, 64};
+            out, bounds_errors, out_row_stride, N, F, B, 64};
   // small launches: 4x more waves (16 bags each) keep more row reads in flight per CU
   if (static_cast<int64_t>(F) * B < (static_cast<int64_t>(1) << 19)) a.bags_per_wave = 16;
   const bool weighted = per_sample_weights != nullptr;
