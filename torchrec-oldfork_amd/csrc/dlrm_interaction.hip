@@ -18,6 +18,7 @@
 //   backward: dX = (G + G^T) X with G the strict upper-triangular matrix of d(flat),
 //             2 x D/16 tiles, K = R; d(dense) additionally receives d(out)[:, :D].
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.hpp"
 
@@ -63,7 +64,7 @@ struct XLoader {
 // the first MFMA.  The summation order over columns is therefore (s, e, q) — the oracle walks the
 // same order (oracle/dlrm_oracle.c), so results stay bit-exact.  LDS only re-stages the 351 pair
 // products for a coalesced store; occupancy is bound by VGPRs (4 waves / SIMD at D = 128), not LDS.
-template <int D>
+template <int D, int ABL = 0>  // ABL: ablation for tuning runs only (1 = no output stores, 2 = no MFMA)
 __global__ __launch_bounds__(256, (D <= 128 ? 4 : 2)) void interaction_fwd_kernel(const float* __restrict__ dense,
                                                                                   const float* __restrict__ sparse,
                                                                                   float* __restrict__ out, int B, int F) {
@@ -81,11 +82,13 @@ __global__ __launch_bounds__(256, (D <= 128 ? 4 : 2)) void interaction_fwd_kerne
   const int row0 = min(r16, R - 1);
   const int row1 = min(16 + r16, R - 1);
   const int stride_b = gridDim.x * 4;
-  for (int b = blockIdx.x * 4 + wave; b < B; b += stride_b) {
+  float4 xa[NS], xb[NS];
+  float4 dpass = make_float4(0.f, 0.f, 0.f, 0.f);  // out[:, :D] = dense[b]
+  // Issues every 16-B load of sample b (operands of both row tiles + the dense pass-through).
+  auto issue_loads = [&](int b) {
     const float* x0 = (row0 == 0 ? dense + static_cast<int64_t>(b) * D
                                  : sparse + (static_cast<int64_t>(b) * F + (row0 - 1)) * D) + 4 * kq;
     const float* x1 = sparse + (static_cast<int64_t>(b) * F + (row1 - 1)) * D + 4 * kq;  // row1 >= 1 when R >= 2
-    float4 xa[NS], xb[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) xa[s] = ld4(x0 + 16 * s);
     if (R > 16) {
@@ -95,8 +98,11 @@ __global__ __launch_bounds__(256, (D <= 128 ? 4 : 2)) void interaction_fwd_kerne
 #pragma unroll
       for (int s = 0; s < NS; ++s) xb[s] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    float4 dpass = make_float4(0.f, 0.f, 0.f, 0.f);  // out[:, :D] = dense[b]
     if (lane < D / 4) dpass = ld4(dense + static_cast<int64_t>(b) * D + lane * 4);
+  };
+  int b = blockIdx.x * 4 + wave;
+  if (b < B) issue_loads(b);
+  for (; b < B; b += stride_b) {
     f32x4 acc00 = {0.f, 0.f, 0.f, 0.f}, acc01 = acc00, acc11 = acc00;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -104,11 +110,21 @@ __global__ __launch_bounds__(256, (D <= 128 ? 4 : 2)) void interaction_fwd_kerne
       const float a1[4] = {xb[s].x, xb[s].y, xb[s].z, xb[s].w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
+        if (ABL == 2) {
+          acc00[0] += a0[e];
+          acc01[0] += a1[e];
+          continue;
+        }
         acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], a0[e], acc00, 0, 0, 0);
         acc01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], a1[e], acc01, 0, 0, 0);
         acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], a1[e], acc11, 0, 0, 0);
       }
     }
+    // The operand registers are dead from here on: the NEXT sample's loads go out now and fly while this
+    // sample's products are re-staged and stored (ablation: the store phase cost 63 of 285 us when it ran
+    // after the loads had been waited for).
+    const float4 dcur = dpass;
+    if (b + stride_b < B) issue_loads(b + stride_b);
     // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -118,16 +134,23 @@ __global__ __launch_bounds__(256, (D <= 128 ? 4 : 2)) void interaction_fwd_kerne
       if (16 + j < R && i < R) zs[triu_index(i, 16 + j, R)] = acc01[q];
       if (i < j && 16 + j < R) zs[triu_index(16 + i, 16 + j, R)] = acc11[q];
     }
-    wave_lds_fence();
+    // zs is private to the wave and LDS operations of a wave execute in order: a compiler barrier is
+    // enough (a memory fence here would also wait for the global loads just issued)
+    __builtin_amdgcn_wave_barrier();
     float* orow = out + static_cast<int64_t>(b) * OUT;
+    if (ABL == 1) {  // keep the computation alive without writing the row
+      if (zs[lane] == 1.2345e-31f) orow[0] = zs[lane];
+      __builtin_amdgcn_wave_barrier();
+      continue;
+    }
     if (lane < D / 4) {  // row stride OUT = D + P is not a multiple of 4 in general: scalar stores
-      orow[lane * 4 + 0] = dpass.x;
-      orow[lane * 4 + 1] = dpass.y;
-      orow[lane * 4 + 2] = dpass.z;
-      orow[lane * 4 + 3] = dpass.w;
+      orow[lane * 4 + 0] = dcur.x;
+      orow[lane * 4 + 1] = dcur.y;
+      orow[lane * 4 + 2] = dcur.z;
+      orow[lane * 4 + 3] = dcur.w;
     }
     for (int p = lane; p < P; p += kWave) orow[D + p] = zs[p];
-    wave_lds_fence();  // zs is rewritten by the next sample
+    __builtin_amdgcn_wave_barrier();  // zs is rewritten by the next sample
   }
 }
 
@@ -306,6 +329,20 @@ extern "C" int tbe_dlrm_interaction_forward_f32(const float* dense, const float*
   // persistent-style: 4 workgroups per CU (2 at D = 256), each wave strides over samples
   const int64_t want = (static_cast<int64_t>(B) + 3) / 4;
   const dim3 grid(static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(want, 256 * (D <= 128 ? 4 : 2)))));
+  static const int ablation = [] {
+    const char* e = getenv("TBE_INTERACTION_ABLATION");  // tuning runs only
+    return e ? atoi(e) : 0;
+  }();
+  if (ablation == 1 && D == 128) {
+    hipLaunchKernelGGL((interaction_fwd_kernel<128, 1>), grid, dim3(256), lds, st, dense, sparse, out, B, F);
+    TBE_CHECK_LAUNCH("tbe_dlrm_interaction_forward_f32");
+    return TBE_OK;
+  }
+  if (ablation == 2 && D == 128) {
+    hipLaunchKernelGGL((interaction_fwd_kernel<128, 2>), grid, dim3(256), lds, st, dense, sparse, out, B, F);
+    TBE_CHECK_LAUNCH("tbe_dlrm_interaction_forward_f32");
+    return TBE_OK;
+  }
 #define TBE_IF(DD) hipLaunchKernelGGL(interaction_fwd_kernel<DD>, grid, dim3(256), lds, st, dense, sparse, out, B, F)
   switch (D) {
     case 16: TBE_IF(16); break;
