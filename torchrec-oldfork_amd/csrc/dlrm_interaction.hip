@@ -26,10 +26,18 @@ namespace tbe {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
+// Synchronisation of a wave's lanes on wave-private LDS data.  The LDS operations of one wave execute in
+// program order, so only the compiler has to be kept from moving them: a wave barrier.  (A memory fence here
+// would also make the wave wait for every outstanding GLOBAL load — exactly the prefetch of the next sample
+// these kernels want to keep in flight.)  TBE_INTERACTION_FENCE=1 at build time restores full fences.
 __device__ __forceinline__ void wave_lds_fence() {
+#ifdef TBE_INTERACTION_FULL_FENCE
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#else
+  __builtin_amdgcn_wave_barrier();
+#endif
 }
 
 // index of pair (i, j), i < j < R, in torch.triu_indices(R, R, offset=1) row-major order
