@@ -65,14 +65,16 @@ def _data(W, fixed_len, weighted, seed=11):
     return per_rank, init
 
 
-def _build_sharded(W, backend_env, weighted, n_rw, dp_max_rows, offload=False, adagrad=False):
+def _build_sharded(W, backend_env, weighted, n_rw, dp_max_rows, offload=False, adagrad=False, mean=False):
     from torchrec_amd.distributed.embeddingbag import ShardedEmbeddingBagCollection
     from torchrec_amd.distributed.planner import EmbeddingShardingPlanner, ParameterConstraints, Topology
     from torchrec_amd.modules.embedding_configs import EmbeddingBagConfig
     from torchrec_amd.modules.embedding_modules import EmbeddingBagCollection
 
     keys = [f"f{i}" for i in range(len(ROWS))]
-    tables = [EmbeddingBagConfig(name=f"t{i}", embedding_dim=D, num_embeddings=ROWS[i], feature_names=[keys[i]])
+    from torchrec_amd.modules.embedding_configs import PoolingType
+    tables = [EmbeddingBagConfig(name=f"t{i}", embedding_dim=D, num_embeddings=ROWS[i], feature_names=[keys[i]],
+                                 pooling=PoolingType.MEAN if mean else PoolingType.SUM)
               for i in range(len(ROWS))]
     ebc = EmbeddingBagCollection(tables, is_weighted=weighted, device=torch.device("meta"))
     # offload: the largest table row-wise in host memory behind the HBM row cache (tiny cache: evictions),
@@ -124,7 +126,7 @@ def _run_rank(sebc, keys, per_rank, init, rank, W, fixed_len, weighted):
     return vals_out.detach().cpu().numpy().copy(), shards
 
 
-def _worker(rank, W, port, fixed_len, weighted, n_rw, dp_max_rows, ret, offload=False, adagrad=False):
+def _worker(rank, W, port, fixed_len, weighted, n_rw, dp_max_rows, ret, offload=False, adagrad=False, mean=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
@@ -135,7 +137,7 @@ def _worker(rank, W, port, fixed_len, weighted, n_rw, dp_max_rows, ret, offload=
 
         per_rank, init = _data(W, fixed_len, weighted)
         keys, plan, sebc = _build_sharded(W, ShardingEnv.from_process_group(dist.group.WORLD), weighted, n_rw, dp_max_rows,
-                                          offload, adagrad)
+                                          offload, adagrad, mean)
         out, shards = _run_rank(sebc, keys, per_rank, init, rank, W, fixed_len, weighted)
         if adagrad:  # per-table row-wise state of the local shards (batched_embedding_kernel.py:133-148)
             states = sebc._emb_module.split_optimizer_states()
@@ -148,8 +150,10 @@ def _worker(rank, W, port, fixed_len, weighted, n_rw, dp_max_rows, ret, offload=
         dist.destroy_process_group()
 
 
-def _check_against_oracle(ret, W, fixed_len, weighted, n_rw, dp_max_rows, adagrad=False):
+def _check_against_oracle(ret, W, fixed_len, weighted, n_rw, dp_max_rows, adagrad=False, mean=False):
     from oracle import oracle
+
+    pool = oracle.POOL_MEAN if mean else oracle.POOL_SUM
 
     per_rank, init = _data(W, fixed_len, weighted)
     F, B = len(ROWS), B_LOCAL
@@ -159,7 +163,7 @@ def _check_against_oracle(ret, W, fixed_len, weighted, n_rw, dp_max_rows, adagra
     for r in range(W):
         lengths, vals, wts, _ = per_rank[r]
         offs = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
-        ref, _ = oracle.tbe_forward(tabs, vals, offs, wts)
+        ref, _ = oracle.tbe_forward(tabs, vals, offs, wts, pool)
         if fixed_len == 1 and not weighted:
             np.testing.assert_array_equal(ret[r][0], ref)  # pure gather: bit-exact through the whole exchange
         else:
@@ -186,7 +190,7 @@ def _check_against_oracle(ret, W, fixed_len, weighted, n_rw, dp_max_rows, adagra
             if kinds[f"t{t}"] == "data_parallel":
                 tabs.weights[t][...] = sgd_tabs.weights[t]
     else:
-        oracle.tbe_backward(tabs, g_vals, g_offs, g_grad, oracle.OPT_EXACT_SGD, LR, g_w)
+        oracle.tbe_backward(tabs, g_vals, g_offs, g_grad, oracle.OPT_EXACT_SGD, LR, g_w, pool)
     seen = {t: 0 for t in range(F)}
     for r in range(W):
         for name, shard in ret[r][1].items():
@@ -238,6 +242,15 @@ def test_sharded_world2_fused_rowwise_adagrad(n_rw, offload):
     ret = mp.Manager().dict()
     mp.spawn(_worker, args=(W, _free_port(), 2, False, n_rw, 10, ret, offload, True), nprocs=W, join=True)
     _check_against_oracle(ret, W, 2, False, n_rw, 10, adagrad=True)
+
+
+def test_sharded_world2_mean_pooling_over_row_wise_shards():
+    """MEAN pooling with row-wise shards + replicated tables: every rank divides its partial sum by the FULL bag
+    length (all ids reach every rank; rows outside its block are masked by the bounds check)."""
+    W = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(W, _free_port(), 0, False, 2, 10, ret, False, False, True), nprocs=W, join=True)
+    _check_against_oracle(ret, W, 0, False, 2, 10, mean=True)
 
 
 def test_sharded_world2_with_host_offloaded_tables():

@@ -44,7 +44,7 @@ def _global_data(W, B_local, fixed_len, weighted, seed=3):
     return per_rank, init
 
 
-def _worker(rank, W, port, fixed_len, weighted, n_rw, ret, dp_max_rows=0):
+def _worker(rank, W, port, fixed_len, weighted, n_rw, ret, dp_max_rows=0, mean=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=W)
@@ -62,7 +62,9 @@ def _worker(rank, W, port, fixed_len, weighted, n_rw, ret, dp_max_rows=0):
         B_local = 6
         per_rank, init = _global_data(W, B_local, fixed_len, weighted)
         keys = [f"f{i}" for i in range(len(ROWS))]
-        tables = [EmbeddingBagConfig(name=f"t{i}", embedding_dim=DIMS[i], num_embeddings=ROWS[i], feature_names=[keys[i]])
+        from torchrec_amd.modules.embedding_configs import PoolingType
+        tables = [EmbeddingBagConfig(name=f"t{i}", embedding_dim=DIMS[i], num_embeddings=ROWS[i], feature_names=[keys[i]],
+                                     pooling=PoolingType.MEAN if mean else PoolingType.SUM)
                   for i in range(len(ROWS))]
         ebc = EmbeddingBagCollection(tables, is_weighted=weighted, device=torch.device("meta"))
         plan = EmbeddingShardingPlanner(Topology(W, "cpu"), num_row_wise=n_rw, dp_max_rows=dp_max_rows).plan_tables(tables)
@@ -102,16 +104,20 @@ def _worker(rank, W, port, fixed_len, weighted, n_rw, ret, dp_max_rows=0):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("fixed_len,weighted,n_rw,dp_max_rows", [
-    (1, False, 1, 0), (2, True, 2, 0), (0, False, 1, 0), (0, True, 0, 0), (1, False, 5, 0),
-    (1, False, 0, 10), (0, True, 1, 25), (2, False, 0, 100)])
-def test_sharded_equals_unsharded_world2(fixed_len, weighted, n_rw, dp_max_rows):
+@pytest.mark.parametrize("fixed_len,weighted,n_rw,dp_max_rows,mean", [
+    (1, False, 1, 0, False), (2, True, 2, 0, False), (0, False, 1, 0, False), (0, True, 0, 0, False),
+    (1, False, 5, 0, False), (1, False, 0, 10, False), (0, True, 1, 25, False), (2, False, 0, 100, False),
+    (0, False, 2, 10, True), (3, False, 5, 0, True)])
+def test_sharded_equals_unsharded_world2(fixed_len, weighted, n_rw, dp_max_rows, mean):
+    """mean=True: MEAN pooling over row-wise shards — every rank divides its partial sum by the FULL bag length
+    (all ids travel to every rank, rows outside its block are masked), so the partial pools still add up."""
     from oracle import oracle
 
     W = 2
+    pool = oracle.POOL_MEAN if mean else oracle.POOL_SUM
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(W, _free_port(), fixed_len, weighted, n_rw, ret, dp_max_rows), nprocs=W, join=True)
+    mp.spawn(_worker, args=(W, _free_port(), fixed_len, weighted, n_rw, ret, dp_max_rows, mean), nprocs=W, join=True)
     per_rank, init = _global_data(W, 6, fixed_len, weighted)
     # unsharded oracle on each rank's batch (forward), then ONE backward over the global batch with
     # grads / W (GRADIENT_DIVISION, comm_ops.py:527-528)
@@ -122,7 +128,7 @@ def test_sharded_equals_unsharded_world2(fixed_len, weighted, n_rw, dp_max_rows)
     for r in range(W):
         lengths, vals, wts, grad = per_rank[r]
         offs = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
-        ref, _ = oracle.tbe_forward(tabs, vals, offs, wts)
+        ref, _ = oracle.tbe_forward(tabs, vals, offs, wts, pool)
         np.testing.assert_allclose(ret[r][0], ref, rtol=1e-5, atol=1e-5)
     kinds = ret[0][2]
     assert sum(1 for k in kinds.values() if k == "row_wise") == n_rw
@@ -137,7 +143,7 @@ def test_sharded_equals_unsharded_world2(fixed_len, weighted, n_rw, dp_max_rows)
            if weighted else None)
     g_grad = np.concatenate([per_rank[r][3] for r in range(W)], axis=0) / W
     g_offs = np.concatenate([[0], np.cumsum(g_len)]).astype(np.int64)
-    oracle.tbe_backward(tabs, g_vals, g_offs, g_grad, oracle.OPT_EXACT_SGD, LR, g_w)
+    oracle.tbe_backward(tabs, g_vals, g_offs, g_grad, oracle.OPT_EXACT_SGD, LR, g_w, pool)
     seen_rows = {t: 0 for t in range(F)}
     for r in range(W):
         for name, (w, row0) in ret[r][1].items():
