@@ -58,6 +58,7 @@ extern "C" {
 #define TBE_OPT_DENSE_GRAD 100
 
 #define TBE_FLAG_UNIFORM_ALIGNED 1
+#define TBE_FLAG_WEIGHTED 2 /* per_sample_weights will be / are given (backward: selects the sort payload layout) */
 
 /* Hyper-parameters of the fused optimizer, passed by value. */
 typedef struct tbe_optimizer_args {
@@ -166,12 +167,30 @@ int tbe_backward_fused_f32(const uint64_t* feat_weights, const int32_t* feat_D,
  * the batch's row keys) can be enqueued on a side stream right after the forward call and overlap
  * the dense MLPs; `apply` then needs only update + fix-up once grad_out exists.
  * tbe_backward_fused_f32 == prepare followed by apply on one stream.  `apply` must receive the
- * workspace a `prepare` call filled for the same (indices, offsets, N, F, B, max_D, key_bits). */
+ * workspace a `prepare` call filled for the same (indices, offsets, N, F, B, max_D, key_bits).
+ * flags (prepare): TBE_FLAG_WEIGHTED when `apply` will be given per_sample_weights (the sort then
+ * carries (bag, position) payloads instead of bag numbers); `apply` must get the same bit. */
 int tbe_backward_prepare(const int64_t* feat_rows, const int64_t* feat_row_base, int32_t F,
                          int32_t B, int32_t max_D, int32_t key_bits, const int64_t* indices,
-                         int64_t N, const int64_t* offsets, int32_t pooling_mode,
+                         int64_t N, const int64_t* offsets, int32_t pooling_mode, int32_t flags,
                          void* workspace, size_t workspace_bytes, int32_t* bounds_errors,
                          void* stream);
+
+/* The stable pair sort the backward and the row cache use, exposed for tests and micro-benchmarks
+ * (no reference counterpart: fbgemm's backward sorts with cub inside the absent submodule).
+ * Sorts n (key, payload) pairs on the low key_bits bits of the keys; equal keys keep input order.
+ * key_bytes / payload_bytes: 4 or 8.  keys / payload are overwritten with the sorted result; keys_tmp /
+ * payload_tmp are scratch of the same size.  workspace >= tbe_sort_pairs_workspace_bytes(n, key_bits).
+ * tbe_debug_sort_timeouts: number of spin-wait give-ups inside the sort since the library was loaded
+ * (must stay 0; synchronises the device). */
+size_t tbe_sort_pairs_workspace_bytes(int64_t n, int32_t key_bits);
+int tbe_sort_pairs(void* keys, void* keys_tmp, void* payload, void* payload_tmp, int64_t n,
+                   int32_t key_bits, int32_t key_bytes, int32_t payload_bytes, void* workspace,
+                   size_t workspace_bytes, void* stream);
+int tbe_debug_sort_timeouts(int64_t* count);
+/* Development aid: device buffer of int64 [7 passes][256 segments][8] that tbe_sort_pairs' pass kernels fill
+ * with 100 MHz wall-clock stamps per phase (NULL switches it off; tools/sstamps.py). */
+int tbe_debug_set_sort_stamps(void* device_buffer);
 int tbe_backward_apply_f32(const uint64_t* feat_weights, const int32_t* feat_D,
                            const int64_t* feat_out_offset, const int64_t* feat_rows,
                            const int64_t* feat_row_base, const uint64_t* feat_state0,

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/tbe_hip.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), "ctypes SIGNATURES out of sync with the header"
-    assert lib.tbe_abi_version() == 1
+    assert lib.tbe_abi_version() == 2
 
 
 def test_argument_validation_happens_before_any_launch():

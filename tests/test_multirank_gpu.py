@@ -20,6 +20,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import _paths  # noqa: F401
+from _results import ResultStore
 from test_sharded_gloo import _free_port
 
 pytestmark = pytest.mark.gpu
@@ -208,7 +209,7 @@ def _check_against_oracle(ret, W, fixed_len, weighted, n_rw, dp_max_rows, adagra
     (1, False, 0, 0), (1, False, 2, 10), (2, True, 1, 0), (0, False, 1, 10), (0, True, 6, 0)])
 def test_sharded_world2_on_one_gpu(fixed_len, weighted, n_rw, dp_max_rows):
     W = 2
-    ret = mp.Manager().dict()
+    ret = ResultStore()
     mp.spawn(_worker, args=(W, _free_port(), fixed_len, weighted, n_rw, dp_max_rows, ret), nprocs=W, join=True)
     _check_against_oracle(ret, W, fixed_len, weighted, n_rw, dp_max_rows)
 
@@ -239,7 +240,7 @@ def test_sharded_world2_fused_rowwise_adagrad(n_rw, offload):
     RW / TW x EXACT_ROWWISE_ADAGRAD): weights AND optimizer state of the shards equal the unsharded run —
     here with the real kernels, incl. row-wise shards behind the HBM row cache."""
     W = 2
-    ret = mp.Manager().dict()
+    ret = ResultStore()
     mp.spawn(_worker, args=(W, _free_port(), 2, False, n_rw, 10, ret, offload, True), nprocs=W, join=True)
     _check_against_oracle(ret, W, 2, False, n_rw, 10, adagrad=True)
 
@@ -248,7 +249,7 @@ def test_sharded_world2_mean_pooling_over_row_wise_shards():
     """MEAN pooling with row-wise shards + replicated tables: every rank divides its partial sum by the FULL bag
     length (all ids reach every rank; rows outside its block are masked by the bounds check)."""
     W = 2
-    ret = mp.Manager().dict()
+    ret = ResultStore()
     mp.spawn(_worker, args=(W, _free_port(), 0, False, 2, 10, ret, False, False, True), nprocs=W, join=True)
     _check_against_oracle(ret, W, 0, False, 2, 10, mean=True)
 
@@ -257,7 +258,7 @@ def test_sharded_world2_with_host_offloaded_tables():
     """Row-wise shards of a table in host memory behind the HBM row cache + a table-wise table in plain
     host-mapped memory (BASELINE config 4's placement), two ranks."""
     W = 2
-    ret = mp.Manager().dict()
+    ret = ResultStore()
     mp.spawn(_worker, args=(W, _free_port(), 2, False, 1, 10, ret, True), nprocs=W, join=True)
     _check_against_oracle(ret, W, 2, False, 1, 10)
 
@@ -265,7 +266,7 @@ def test_sharded_world2_with_host_offloaded_tables():
 @pytest.mark.parametrize("fixed_len,weighted,dp_max_rows", [(1, False, 10), (0, True, 0)])
 def test_exchange_through_rccl_world1(fixed_len, weighted, dp_max_rows):
     """The asynchronous id + pooled all-to-all and the exchange kernels over a real RCCL group."""
-    ret = mp.Manager().dict()
+    ret = ResultStore()
     mp.spawn(_rccl_worker, args=(_free_port(), fixed_len, weighted, dp_max_rows, ret), nprocs=1, join=True)
     _check_against_oracle(ret, 1, fixed_len, weighted, 0, dp_max_rows)
 
@@ -385,7 +386,7 @@ def test_dlrm_train_world2_on_one_gpu_matches_world1(hip_graphs):
     of DDP (models/dlrm.py capture_hip_graphs(flat_grads=True)); ranks start from different dense weights
     and must end identical (the rank-0 broadcast DDP would have done)."""
     W = 2
-    ret = mp.Manager().dict()
+    ret = ResultStore()
     mp.spawn(_e2e_worker, args=(W, _free_port(), ret, hip_graphs), nprocs=W, join=True)
     from torchrec_amd.distributed.types import ShardingEnv
 
@@ -459,6 +460,6 @@ def test_sharded_sequence_embedding_world2_on_one_gpu(row_wise):
     from test_sharded_gloo import _check_seq
 
     W = 2
-    ret = mp.Manager().dict()
+    ret = ResultStore()
     mp.spawn(_seq_gpu_worker, args=(W, _free_port(), ret, row_wise), nprocs=W, join=True)
     _check_seq(ret, W)

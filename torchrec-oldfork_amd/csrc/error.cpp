@@ -15,4 +15,4 @@ void set_error(const char* fmt, ...) {
 }  // namespace tbe
 
 extern "C" const char* tbe_last_error(void) { return tbe::g_err; }
-extern "C" int32_t tbe_abi_version(void) { return 1; }
+extern "C" int32_t tbe_abi_version(void) { return 2; }

@@ -9,9 +9,11 @@
 //
 // Pipeline (all on `stream`, no host sync, no atomics on floats => bitwise reproducible):
 //  1. linearize : key[p] = feat_row_base[f] + indices[p]  (invalid index -> sentinel),
-//                 payload[p] = (bag << 32) | p             (thread per bag, coalesced at L = 1)
+//                 payload[p] = bag  or  (bag << 32) | p    (thread per bag, coalesced at L = 1)
 //  2. sort      : stable LSD radix sort of (key, payload) on the low key_bits bits
-//                 (hand-written, radix_sort.hpp: 8-bit digits, ballot-based stable ranking)
+//                 (hand-written, radix_sort.hpp: one launch per 10-bit digit pass).  The payload is
+//                 the 32-bit bag number for pooled lookups without per-sample weights (the update
+//                 needs nothing else), (bag << 32) | position otherwise.
 //  3. update    : the sorted contributions are cut into fixed chunks of C; one G-lane group
 //                 walks a chunk, 4 gradient rows + 4 weight rows in flight, accumulates
 //                 runs of equal keys in registers and applies the optimizer when a run
@@ -55,7 +57,7 @@ struct BwdArgs {
   float bias2;  // ADAM: 1 - beta2^t
   // workspace
   void* keys_sorted;
-  const uint64_t* payload_sorted;
+  const void* payload_sorted;  // uint32 bag numbers, or uint64 (bag << 32) | position
   float* partial_first;  // [nchunks][max_D_pad]
   float* partial_last;   // [nchunks][max_D_pad]
   int32_t* origin_list;  // [nchunks] chunks whose last run continues (compacted, any order)
@@ -66,11 +68,38 @@ struct BwdArgs {
   unsigned long long* unique_rows;  // optional profiling counter: table rows updated
 };
 
-template <typename KeyT>
+// One launch instead of two memsets: every key starts as all-ones (= invalid: positions that inconsistent
+// offsets leave uncovered must not reach the update kernel as garbage rows) and the sort's state block
+// (tickets, digit totals, histogram rows; origin_count lives among the tickets) starts as zero.
+__global__ __launch_bounds__(256) void bwd_fill_kernel(uint4* __restrict__ keys16, int64_t n_keys16,
+                                                        uint4* __restrict__ state16, int64_t n_state16) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  for (int64_t i = t; i < n_keys16; i += stride) keys16[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+  for (int64_t i = t; i < n_state16; i += stride) state16[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+template <typename PayT>
+__device__ __forceinline__ PayT make_payload(uint32_t bag, uint32_t pos) {
+  if constexpr (sizeof(PayT) == 4) return bag;
+  else return (static_cast<uint64_t>(bag) << 32) | pos;
+}
+template <typename PayT>
+__device__ __forceinline__ uint32_t payload_bag(PayT p) {
+  if constexpr (sizeof(PayT) == 4) return p;
+  else return static_cast<uint32_t>(p >> 32);
+}
+template <typename PayT>
+__device__ __forceinline__ uint32_t payload_pos(PayT p) {
+  if constexpr (sizeof(PayT) == 4) return 0u;  // never used: no per-sample weights, pooled
+  else return static_cast<uint32_t>(p);
+}
+
+template <typename KeyT, typename PayT>
 __global__ __launch_bounds__(256) void bwd_linearize_pooled_kernel(
     const int64_t* __restrict__ indices, const int64_t* __restrict__ offsets,
     const int64_t* __restrict__ feat_rows, const int64_t* __restrict__ feat_row_base, int F, int B,
-    int64_t N, int key_bits, KeyT* __restrict__ keys, uint64_t* __restrict__ payload,
+    int64_t N, int key_bits, KeyT* __restrict__ keys, PayT* __restrict__ payload,
     int32_t* bounds_errors) {
   const int64_t bag = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (bag >= static_cast<int64_t>(F) * B) return;
@@ -92,7 +121,7 @@ __global__ __launch_bounds__(256) void bwd_linearize_pooled_kernel(
     const bool ok = static_cast<uint64_t>(idx) < static_cast<uint64_t>(rows);
     if (!ok) ++nbad;
     keys[p] = ok ? static_cast<KeyT>(base + idx) : sentinel;
-    payload[p] = (static_cast<uint64_t>(bag) << 32) | static_cast<uint32_t>(p);
+    payload[p] = make_payload<PayT>(static_cast<uint32_t>(bag), static_cast<uint32_t>(p));
   }
   if (nbad > 0 && bounds_errors != nullptr) atomicAdd(bounds_errors, nbad);
 }
@@ -277,7 +306,7 @@ struct BwdUnroll {
 
 // FAST: every feature has dim a.fast_D (multiple of 4), SUM pooling, no per-sample weights, every
 // row base 16-B aligned (TBE_FLAG_UNIFORM_ALIGNED from the host) — the Criteo configuration.
-template <typename KeyT, int G, int NV, int OPTC, bool FAST, int U, int MINW>
+template <typename KeyT, typename PayT, int G, int NV, int OPTC, bool FAST, int U, int MINW>
 __global__ __launch_bounds__(256, MINW) void bwd_update_kernel(BwdArgs a) {
   constexpr int NG = kWave / G;
   const int lane = threadIdx.x & 63;
@@ -293,6 +322,7 @@ __global__ __launch_bounds__(256, MINW) void bwd_update_kernel(BwdArgs a) {
   const bool active = chunk < nchunks;
 
   const KeyT* __restrict__ skey = static_cast<const KeyT*>(a.keys_sorted);
+  const PayT* __restrict__ spay = static_cast<const PayT*>(a.payload_sorted);
   const KeyT sentinel = static_cast<KeyT>((a.key_bits >= 64) ? ~0ull : ((1ull << a.key_bits) - 1ull));
   const bool nobag = a.pooling_mode == TBE_POOL_NONE;
   const bool mean = a.pooling_mode == TBE_POOL_MEAN;
@@ -319,16 +349,16 @@ __global__ __launch_bounds__(256, MINW) void bwd_update_kernel(BwdArgs a) {
     const bool in = active && kk < i1;
     KeyT key_k = sentinel;
     KeyT keyn_k = sentinel;
-    uint64_t pay_k = 0;
+    PayT pay_k = 0;
     if (in) {
       key_k = skey[kk];
-      pay_k = a.payload_sorted[kk];
+      pay_k = spay[kk];
       if (kk + 1 < a.N) keyn_k = skey[kk + 1];
     }
     const bool valid_k = in && key_k < sentinel;  // sentinel = invalid id; anything above = never written
     const bool last_k = valid_k && (key_k != keyn_k || kk + 1 >= a.N);
-    const uint32_t bag_k = static_cast<uint32_t>(pay_k >> 32);
-    const uint32_t pos_k = static_cast<uint32_t>(pay_k);
+    const uint32_t bag_k = payload_bag<PayT>(pay_k);
+    const uint32_t pos_k = payload_pos<PayT>(pay_k);
     const int f_k = valid_k ? static_cast<int>(bag_k / static_cast<uint32_t>(a.B)) : 0;
     const int b_k = static_cast<int>(bag_k - static_cast<uint32_t>(f_k) * static_cast<uint32_t>(a.B));
     const int D_k = FAST ? a.fast_D : a.feat_D[f_k];
@@ -476,7 +506,7 @@ __device__ __forceinline__ void sum_partials(const float* __restrict__ base, int
   }
 }
 
-template <typename KeyT, int G, int NV>
+template <typename KeyT, typename PayT, int G, int NV>
 __global__ __launch_bounds__(256) void bwd_fixup_kernel(BwdArgs a) {
   constexpr int NG = kWave / G;
   constexpr int NGB = 4 * NG;
@@ -491,6 +521,7 @@ __global__ __launch_bounds__(256) void bwd_fixup_kernel(BwdArgs a) {
   const int q = wave * NG + g;  // group index inside the block
   const int64_t nchunks = (a.N + a.C - 1) / a.C;
   const KeyT* __restrict__ skey = static_cast<const KeyT*>(a.keys_sorted);
+  const PayT* __restrict__ spay = static_cast<const PayT*>(a.payload_sorted);
   const int count = *a.origin_count;
 
   for (int base = blockIdx.x * 4; base < count; base += gridDim.x * 4) {  // block-uniform
@@ -517,8 +548,8 @@ __global__ __launch_bounds__(256) void bwd_fixup_kernel(BwdArgs a) {
           long_len[s] = len;
         }
       } else {
-        const uint64_t pay = a.payload_sorted[(chunk + 1) * a.C - 1];
-        const int f = static_cast<int>(static_cast<uint32_t>(pay >> 32) / static_cast<uint32_t>(a.B));
+        const PayT pay = spay[(chunk + 1) * a.C - 1];
+        const int f = static_cast<int>(payload_bag<PayT>(pay) / static_cast<uint32_t>(a.B));
         const int D = a.feat_D[f];
         const int64_t lrow = static_cast<int64_t>(key_run) - a.feat_row_base[f];
         float* wrow = reinterpret_cast<float*>(a.feat_weights[f]) + lrow * D;
@@ -568,8 +599,8 @@ __global__ __launch_bounds__(256) void bwd_fixup_kernel(BwdArgs a) {
       const int64_t chunk = long_chunk[s];
       const int len = long_len[s];
       const KeyT key_run = skey[(chunk + 1) * a.C - 1];
-      const uint64_t pay = a.payload_sorted[(chunk + 1) * a.C - 1];
-      const int f = static_cast<int>(static_cast<uint32_t>(pay >> 32) / static_cast<uint32_t>(a.B));
+      const PayT pay = spay[(chunk + 1) * a.C - 1];
+      const int f = static_cast<int>(payload_bag<PayT>(pay) / static_cast<uint32_t>(a.B));
       const int D = a.feat_D[f];
       const int64_t lrow = static_cast<int64_t>(key_run) - a.feat_row_base[f];
       float* wrow = reinterpret_cast<float*>(a.feat_weights[f]) + lrow * D;
@@ -623,8 +654,8 @@ static int pick_chunk(int64_t N) {
 struct BwdWorkspace {
   void* keys_in;
   void* keys_out;
-  uint64_t* pay_in;
-  uint64_t* pay_out;
+  void* pay_in;   // uint32 or uint64 payloads (sized for uint64)
+  void* pay_out;
   float* partial_first;
   float* partial_last;
   int32_t* origin_list;
@@ -643,18 +674,19 @@ static int carve(void* ws, int64_t N, int32_t max_D, int32_t key_bits, BwdWorksp
   Carver c(ws);
   out->keys_in = c.take_bytes(N * ksz);
   out->keys_out = c.take_bytes(N * ksz);
-  out->pay_in = c.take<uint64_t>(N);
-  out->pay_out = c.take<uint64_t>(N);
+  out->pay_in = c.take_bytes(N * sizeof(uint64_t));
+  out->pay_out = c.take_bytes(N * sizeof(uint64_t));
   out->partial_first = c.take<float>(nchunks * max_D_pad);
   out->partial_last = c.take<float>(nchunks * max_D_pad);
   out->origin_list = c.take<int32_t>(nchunks);
-  out->origin_count = c.take<int32_t>(1);
   out->sort = radix_carve(c.take_bytes(sort_bytes), N, key_bits);
+  // zeroed together with the sort's tickets by the one memset radix_sort_pairs issues
+  out->origin_count = out->sort.tickets ? reinterpret_cast<int32_t*>(out->sort.tickets + 8) : nullptr;
   out->total = c.total();
   return TBE_OK;
 }
 
-template <typename KeyT, int G, int NV>
+template <typename KeyT, typename PayT, int G, int NV>
 static int launch_update(const BwdArgs& a, hipStream_t st) {
   constexpr int NG = kWave / G;
   const int64_t nchunks = (a.N + a.C - 1) / a.C;
@@ -670,7 +702,7 @@ static int launch_update(const BwdArgs& a, hipStream_t st) {
     const bool fast = a.fast_D > 0 && a.pooling_mode == TBE_POOL_SUM && a.psw == nullptr;
     const int oc = a.opt.optimizer;
 #define TBE_UPD(OPTC, FAST_, UU, MW) \
-  hipLaunchKernelGGL((bwd_update_kernel<KeyT, G, NV, OPTC, FAST_, UU, MW>), dim3(grid), dim3(256), 0, st, a)
+  hipLaunchKernelGGL((bwd_update_kernel<KeyT, PayT, G, NV, OPTC, FAST_, UU, MW>), dim3(grid), dim3(256), 0, st, a)
     if (fast && G == 32 && NV == 1 && oc == TBE_OPT_EXACT_SGD) {
       switch (variant) {
         case 1: TBE_UPD(TBE_OPT_EXACT_SGD, true, 4, 8); break;
@@ -688,7 +720,7 @@ static int launch_update(const BwdArgs& a, hipStream_t st) {
   }
   TBE_CHECK_LAUNCH("tbe_backward update");
   const unsigned fgrid = static_cast<unsigned>(std::min<int64_t>((nchunks + 3) / 4, 1024));
-  hipLaunchKernelGGL((bwd_fixup_kernel<KeyT, G, NV>), dim3(fgrid), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((bwd_fixup_kernel<KeyT, PayT, G, NV>), dim3(fgrid), dim3(256), 0, st, a);
   TBE_CHECK_LAUNCH("tbe_backward fixup");
   return TBE_OK;
 }
@@ -696,51 +728,51 @@ static int launch_update(const BwdArgs& a, hipStream_t st) {
 constexpr int kPhasePrepare = 1;  // gradient-independent: linearize + sort
 constexpr int kPhaseApply = 2;    // update + fix-up
 
-template <typename KeyT>
+template <typename KeyT, typename PayT>
 static int run_backward(BwdArgs a, const BwdWorkspace& w, int32_t max_D, hipStream_t st, int phase) {
   ProfileSpan total_span(phase == kPhasePrepare ? -1 : TBE_PROFILE_BWD_TOTAL, st);
   KeyT* kin = static_cast<KeyT*>(w.keys_in);
   KeyT* kout = static_cast<KeyT*>(w.keys_out);
+  PayT* pin = static_cast<PayT*>(w.pay_in);
+  PayT* pout = static_cast<PayT*>(w.pay_out);
   // the sort ping-pongs between the two buffer pairs: an odd number of passes ends in the second
   const bool in_second = (radix_passes(a.key_bits) & 1) != 0;
   a.keys_sorted = in_second ? static_cast<void*>(kout) : static_cast<void*>(kin);
-  a.payload_sorted = in_second ? w.pay_out : w.pay_in;
+  a.payload_sorted = in_second ? static_cast<void*>(pout) : static_cast<void*>(pin);
   if (phase & kPhasePrepare) {
-  ProfileSpan prep_span(TBE_PROFILE_BWD_PREPARE, st);
-  if (a.pooling_mode == TBE_POOL_NONE) {
-    const size_t lds = (static_cast<size_t>(a.F) + 1) * sizeof(int64_t);
-    const unsigned grid = static_cast<unsigned>(std::min<int64_t>((a.N + 255) / 256, 256 * 16));
-    hipLaunchKernelGGL((bwd_linearize_nobag_kernel<KeyT>), dim3(grid), dim3(256), lds, st, a.indices,
-                       a.offsets, a.feat_rows, a.feat_row_base, a.F, a.B, a.N, a.key_bits, kin,
-                       w.pay_in, a.bounds_errors);
-  } else {
-    const int64_t nbags = static_cast<int64_t>(a.F) * a.B;
-    const unsigned grid = static_cast<unsigned>((nbags + 255) / 256);
-    // every key starts as all-ones (= invalid): positions that inconsistent offsets leave uncovered must not
-    // reach the update kernel as garbage rows
-    if (hipMemsetAsync(kin, 0xFF, static_cast<size_t>(a.N) * sizeof(KeyT), st) != hipSuccess) {
-      set_error("tbe_backward: hipMemsetAsync failed");
-      return TBE_ERR_LAUNCH;
+    ProfileSpan prep_span(TBE_PROFILE_BWD_PREPARE, st);
+    {
+      // 16-B units; both buffers start 256-B aligned and the carver pads each to the next 256-B boundary
+      const int64_t n_keys16 = a.pooling_mode == TBE_POOL_NONE ? 0 : (a.N * static_cast<int64_t>(sizeof(KeyT)) + 15) / 16;
+      const int64_t n_state16 = (static_cast<int64_t>(radix_state_words(a.N, a.key_bits, sizeof(KeyT) + sizeof(PayT))) + 3) / 4;
+      const unsigned grid = static_cast<unsigned>(std::min<int64_t>((std::max(n_keys16, n_state16) + 255) / 256, 2048));
+      hipLaunchKernelGGL(bwd_fill_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<uint4*>(kin), n_keys16,
+                         reinterpret_cast<uint4*>(w.sort.state), n_state16);
     }
-    hipLaunchKernelGGL((bwd_linearize_pooled_kernel<KeyT>), dim3(grid), dim3(256), 0, st, a.indices,
-                       a.offsets, a.feat_rows, a.feat_row_base, a.F, a.B, a.N, a.key_bits, kin, w.pay_in,
-                       a.bounds_errors);
-  }
-  TBE_CHECK_LAUNCH("tbe_backward linearize");
-  if (hipMemsetAsync(a.origin_count, 0, sizeof(int32_t), st) != hipSuccess) {
-    set_error("tbe_backward: hipMemsetAsync failed");
-    return TBE_ERR_LAUNCH;
-  }
-  const int where = radix_sort_pairs<KeyT>(kin, kout, w.pay_in, w.pay_out, a.N, a.key_bits, w.sort, st);
-  if (where < 0) return where;
+    if (a.pooling_mode == TBE_POOL_NONE) {
+      if constexpr (sizeof(PayT) == 8) {
+        const size_t lds = (static_cast<size_t>(a.F) + 1) * sizeof(int64_t);
+        const unsigned grid = static_cast<unsigned>(std::min<int64_t>((a.N + 255) / 256, 256 * 16));
+        hipLaunchKernelGGL((bwd_linearize_nobag_kernel<KeyT>), dim3(grid), dim3(256), lds, st, a.indices, a.offsets,
+                           a.feat_rows, a.feat_row_base, a.F, a.B, a.N, a.key_bits, kin, pin, a.bounds_errors);
+      }
+    } else {
+      const int64_t nbags = static_cast<int64_t>(a.F) * a.B;
+      const unsigned grid = static_cast<unsigned>((nbags + 255) / 256);
+      hipLaunchKernelGGL((bwd_linearize_pooled_kernel<KeyT, PayT>), dim3(grid), dim3(256), 0, st, a.indices, a.offsets,
+                         a.feat_rows, a.feat_row_base, a.F, a.B, a.N, a.key_bits, kin, pin, a.bounds_errors);
+    }
+    TBE_CHECK_LAUNCH("tbe_backward linearize");
+    const int where = radix_sort_pairs<KeyT, PayT>(kin, kout, pin, pout, a.N, a.key_bits, w.sort, st, kSortStateZeroed);
+    if (where < 0) return where;
   }  // prepare
   if (!(phase & kPhaseApply)) return TBE_OK;
-  if (max_D <= 64) return launch_update<KeyT, 16, 1>(a, st);
-  if (max_D <= 128) return launch_update<KeyT, 32, 1>(a, st);
-  if (max_D <= 256) return launch_update<KeyT, 64, 1>(a, st);
-  if (max_D <= 512) return launch_update<KeyT, 64, 2>(a, st);
-  if (max_D <= 1024) return launch_update<KeyT, 64, 4>(a, st);
-  return launch_update<KeyT, 64, 8>(a, st);
+  if (max_D <= 64) return launch_update<KeyT, PayT, 16, 1>(a, st);
+  if (max_D <= 128) return launch_update<KeyT, PayT, 32, 1>(a, st);
+  if (max_D <= 256) return launch_update<KeyT, PayT, 64, 1>(a, st);
+  if (max_D <= 512) return launch_update<KeyT, PayT, 64, 2>(a, st);
+  if (max_D <= 1024) return launch_update<KeyT, PayT, 64, 4>(a, st);
+  return launch_update<KeyT, PayT, 64, 8>(a, st);
 }
 
 }  // namespace tbe
@@ -777,6 +809,10 @@ static int backward_entry(
   TBE_REQUIRE(static_cast<int64_t>(F) * B < (1ll << 32) && N < (1ll << 32),
               "tbe_backward_fused_f32: F*B and N must be < 2^32");
   TBE_REQUIRE(grad_row_stride > 0, "tbe_backward_fused_f32: grad_row_stride <= 0");
+  if (phase == (kPhasePrepare | kPhaseApply) && per_sample_weights != nullptr) flags |= TBE_FLAG_WEIGHTED;
+  TBE_REQUIRE(per_sample_weights == nullptr || (flags & TBE_FLAG_WEIGHTED) != 0,
+              "tbe_backward_apply_f32: per_sample_weights given but TBE_FLAG_WEIGHTED not set (it must be set in "
+              "both tbe_backward_prepare and tbe_backward_apply_f32)");
   switch (opt.optimizer) {
     case TBE_OPT_EXACT_SGD:
       break;
@@ -841,8 +877,12 @@ static int backward_entry(
   a.bounds_errors = bounds_errors;
   a.unique_rows = (phase & kPhaseApply) ? profile_unique_rows_counter() : nullptr;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (key_bits > 32) return run_backward<uint64_t>(a, w, max_D, st, phase);
-  return run_backward<uint32_t>(a, w, max_D, st, phase);
+  // payload width: the bag number alone unless positions are needed (per-sample weights, unpooled rows)
+  static const bool force_wide = getenv("TBE_BWD_WIDE_PAYLOAD") != nullptr;  // development A/B switch
+  const bool wide = force_wide || pooling_mode == TBE_POOL_NONE || (flags & TBE_FLAG_WEIGHTED) != 0;
+  if (key_bits > 32)
+    return wide ? run_backward<uint64_t, uint64_t>(a, w, max_D, st, phase) : run_backward<uint64_t, uint32_t>(a, w, max_D, st, phase);
+  return wide ? run_backward<uint32_t, uint64_t>(a, w, max_D, st, phase) : run_backward<uint32_t, uint32_t>(a, w, max_D, st, phase);
 }
 
 extern "C" int tbe_backward_fused_f32(
@@ -861,12 +901,12 @@ extern "C" int tbe_backward_fused_f32(
 
 extern "C" int tbe_backward_prepare(const int64_t* feat_rows, const int64_t* feat_row_base, int32_t F, int32_t B,
                                     int32_t max_D, int32_t key_bits, const int64_t* indices, int64_t N,
-                                    const int64_t* offsets, int32_t pooling_mode, void* workspace,
+                                    const int64_t* offsets, int32_t pooling_mode, int32_t flags, void* workspace,
                                     size_t workspace_bytes, int32_t* bounds_errors, void* stream) {
   tbe_optimizer_args opt{};
   return backward_entry(nullptr, nullptr, nullptr, feat_rows, feat_row_base, nullptr, nullptr, F, B, max_D, key_bits,
-                        indices, N, offsets, nullptr, pooling_mode, nullptr, 1, opt, 0, workspace, workspace_bytes,
-                        bounds_errors, stream, kPhasePrepare);
+                        indices, N, offsets, nullptr, pooling_mode, nullptr, 1, opt, flags & TBE_FLAG_WEIGHTED, workspace,
+                        workspace_bytes, bounds_errors, stream, kPhasePrepare);
 }
 
 extern "C" int tbe_backward_apply_f32(
@@ -880,4 +920,70 @@ extern "C" int tbe_backward_apply_f32(
   return backward_entry(feat_weights, feat_D, feat_out_offset, feat_rows, feat_row_base, feat_state0, feat_state1, F,
                         B, max_D, key_bits, indices, N, offsets, per_sample_weights, pooling_mode, grad_out,
                         grad_row_stride, opt, flags, workspace, workspace_bytes, nullptr, stream, kPhaseApply);
+}
+
+// ---- the pair sort as a public entry (tests, micro-benchmarks) ---------------------------------------
+extern "C" size_t tbe_sort_pairs_workspace_bytes(int64_t n, int32_t key_bits) {
+  if (key_bits < 1 || key_bits > 64) return 0;
+  return radix_carve(nullptr, n, key_bits).bytes;
+}
+
+extern "C" int tbe_sort_pairs(void* keys, void* keys_tmp, void* payload, void* payload_tmp, int64_t n, int32_t key_bits,
+                              int32_t key_bytes, int32_t payload_bytes, void* workspace, size_t workspace_bytes,
+                              void* stream) {
+  TBE_REQUIRE(n >= 0, "tbe_sort_pairs: n < 0");
+  TBE_REQUIRE(key_bytes == 4 || key_bytes == 8, "tbe_sort_pairs: key_bytes must be 4 or 8");
+  TBE_REQUIRE(payload_bytes == 4 || payload_bytes == 8, "tbe_sort_pairs: payload_bytes must be 4 or 8");
+  TBE_REQUIRE(key_bits >= 1 && key_bits <= 8 * key_bytes, "tbe_sort_pairs: key_bits=%d", key_bits);
+  if (n == 0) return TBE_OK;
+  TBE_REQUIRE(keys && keys_tmp && payload && payload_tmp && workspace, "tbe_sort_pairs: null pointer");
+  TBE_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "tbe_sort_pairs: workspace must be 256-B aligned");
+  const RadixWorkspace ws = radix_carve(workspace, n, key_bits);
+  if (ws.bytes > workspace_bytes) {
+    set_error("tbe_sort_pairs: workspace too small (%zu < %zu)", workspace_bytes, ws.bytes);
+    return TBE_ERR_WORKSPACE;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int where;
+  if (key_bytes == 4 && payload_bytes == 4)
+    where = radix_sort_pairs<uint32_t, uint32_t>(static_cast<uint32_t*>(keys), static_cast<uint32_t*>(keys_tmp),
+                                                 static_cast<uint32_t*>(payload), static_cast<uint32_t*>(payload_tmp), n,
+                                                 key_bits, ws, st);
+  else if (key_bytes == 4)
+    where = radix_sort_pairs<uint32_t, uint64_t>(static_cast<uint32_t*>(keys), static_cast<uint32_t*>(keys_tmp),
+                                                 static_cast<uint64_t*>(payload), static_cast<uint64_t*>(payload_tmp), n,
+                                                 key_bits, ws, st);
+  else if (payload_bytes == 4)
+    where = radix_sort_pairs<uint64_t, uint32_t>(static_cast<uint64_t*>(keys), static_cast<uint64_t*>(keys_tmp),
+                                                 static_cast<uint32_t*>(payload), static_cast<uint32_t*>(payload_tmp), n,
+                                                 key_bits, ws, st);
+  else
+    where = radix_sort_pairs<uint64_t, uint64_t>(static_cast<uint64_t*>(keys), static_cast<uint64_t*>(keys_tmp),
+                                                 static_cast<uint64_t*>(payload), static_cast<uint64_t*>(payload_tmp), n,
+                                                 key_bits, ws, st);
+  if (where < 0) return where;
+  if (where == 1) {
+    if (hipMemcpyAsync(keys, keys_tmp, static_cast<size_t>(n) * key_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(payload, payload_tmp, static_cast<size_t>(n) * payload_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+      set_error("tbe_sort_pairs: copy back failed");
+      return TBE_ERR_LAUNCH;
+    }
+  }
+  return TBE_OK;
+}
+
+extern "C" int tbe_debug_sort_timeouts(int64_t* count) {
+  TBE_REQUIRE(count != nullptr, "tbe_debug_sort_timeouts: null pointer");
+  unsigned int v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_sort_timeouts), sizeof(v)) != hipSuccess) {
+    set_error("tbe_debug_sort_timeouts: hipMemcpyFromSymbol failed");
+    return TBE_ERR_LAUNCH;
+  }
+  *count = v;
+  return TBE_OK;
+}
+
+extern "C" int tbe_debug_set_sort_stamps(void* device_buffer) {
+  g_sort_stamps = static_cast<uint64_t*>(device_buffer);
+  return TBE_OK;
 }

@@ -374,7 +374,7 @@ extern "C" int tbe_cache_prefetch(const tbe_cache_desc* desc, const int32_t* fea
   hipLaunchKernelGGL(cache_linearize_kernel, dim3(std::min<unsigned>(gridN, 256 * 16)), dim3(256), lds, st, indices, offsets,
                      feat_cached_table, feat_rows, c.tab_key_base, F, B, N, sentinel, w.k0, w.p0, remapped_indices);
   TBE_CHECK_LAUNCH("tbe_cache_prefetch linearize");
-  const int where = radix_sort_pairs<uint64_t>(w.k0, w.k1, w.p0, w.p1, N, key_bits, w.sort, st);
+  const int where = radix_sort_pairs<uint64_t, uint64_t>(w.k0, w.k1, w.p0, w.p1, N, key_bits, w.sort, st);
   if (where < 0) return where;
   const bool in_second = (radix_passes(key_bits) & 1) != 0;
   const uint64_t* sk = in_second ? w.k1 : w.k0;

@@ -72,9 +72,16 @@ SIGNATURES = {
     ),
     "tbe_backward_prepare": (
         ctypes.c_int,
-        [c_void_p, c_void_p, c_i32, c_i32, c_i32, c_i32, c_void_p, c_i64, c_void_p, c_i32, c_void_p,
+        [c_void_p, c_void_p, c_i32, c_i32, c_i32, c_i32, c_void_p, c_i64, c_void_p, c_i32, c_i32, c_void_p,
          c_size, c_void_p, c_void_p],
     ),
+    "tbe_sort_pairs_workspace_bytes": (c_size, [c_i64, c_i32]),
+    "tbe_sort_pairs": (
+        ctypes.c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i32, c_i32, c_i32, c_void_p, c_size, c_void_p],
+    ),
+    "tbe_debug_sort_timeouts": (ctypes.c_int, [ctypes.POINTER(c_i64)]),
+    "tbe_debug_set_sort_stamps": (ctypes.c_int, [c_void_p]),
     "tbe_backward_apply_f32": (
         ctypes.c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32,

@@ -25,6 +25,9 @@ from .split_embedding_configs import EmbOptimType as OptimType
 from .split_embedding_configs import SparseType
 
 
+_FLAG_WEIGHTED = 2  # TBE_FLAG_WEIGHTED (include/tbe_hip.h)
+
+
 class EmbeddingLocation(enum.IntEnum):
     DEVICE = 0
     MANAGED = 1
@@ -544,7 +547,7 @@ class _TBEBase(nn.Module):
             )
         return out
 
-    def _prepare_backward(self, indices, offsets, B: int):
+    def _prepare_backward(self, indices, offsets, B: int, weighted: bool = False):
         """Enqueues the gradient-independent half of backward (linearize + stable sort of the row
         keys) on a side stream, right after the forward kernel, so that it overlaps whatever the
         caller does between forward and backward (the dense MLPs).  Returns (workspace, event)."""
@@ -569,7 +572,8 @@ class _TBEBase(nn.Module):
             check(
                 lib.tbe_backward_prepare(ptr(lay.feat_rows), ptr(lay.feat_row_base), self.F, B, self.max_D,
                                          self.key_bits, ptr(indices), N, ptr(offsets), int(self.pooling_mode),
-                                         ptr(ws), ws.numel(), ptr(self._errors()), side.cuda_stream),
+                                         _FLAG_WEIGHTED if weighted else 0, ptr(ws), ws.numel(),
+                                         ptr(self._errors()), side.cuda_stream),
                 "tbe_backward_prepare",
             )
             ev = torch.cuda.Event()
@@ -599,6 +603,8 @@ class _TBEBase(nn.Module):
         # out 16-B aligned by _init_tables; out offsets are then multiples of 4 as well)
         flags = 1 if (len(set(self.dims_per_table)) == 1 and self.max_D % 4 == 0 and stride % 4 == 0
                       and state0_override is None) else 0
+        if per_sample_weights is not None:
+            flags |= _FLAG_WEIGHTED  # the sort payload then carries positions too (set in prepare as well)
         with torch.cuda.device(dev):
             if prepared is not None:
                 ws, ev = prepared
@@ -638,7 +644,8 @@ class _FusedLookupInto(torch.autograd.Function):
         ctx.module, ctx.B, ctx.layout = module, B, (out_off, stride)
         ctx.save_for_backward(indices, offsets, per_sample_weights)
         module._forward_impl(indices, offsets, per_sample_weights, B, into=(out, out_off, stride))
-        ctx.prepared = module._prepare_backward(indices, offsets, B) if prepare else None
+        ctx.prepared = (module._prepare_backward(indices, offsets, B, per_sample_weights is not None)
+                        if prepare else None)
         ctx.mark_dirty(out)
         return out
 
@@ -684,7 +691,8 @@ class _FusedLookup(torch.autograd.Function):
         ctx.B = B
         ctx.save_for_backward(indices, offsets, per_sample_weights)
         out = module._forward_impl(indices, offsets, per_sample_weights, B)
-        ctx.prepared = module._prepare_backward(indices, offsets, B) if prepare else None
+        ctx.prepared = (module._prepare_backward(indices, offsets, B, per_sample_weights is not None)
+                        if prepare else None)
         return out
 
     @staticmethod
