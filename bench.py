@@ -11,47 +11,36 @@ resident in HBM when the timed region starts.  Scaling is STRONG: the global bat
 65 536 and is split over the ranks, as in the reference's published 8-GPU run
 (examples/dlrm/README.MD:38-45).
 
-Launch: `python bench.py --gpus 1 ...` or, for N > 1,
-`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-   --master-port P bench.py --gpus N --steps K --warmup W`.
+Launch: `python bench.py --gpus N --steps K --warmup W` for any N.  With N > 1 and no WORLD_SIZE in
+the environment this process starts N fresh rank processes itself (`python -m torch.distributed.run
+--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`, the command of examples/dlrm/README.MD:17-28)
+BEFORE anything here touches the GPU (torch is not even imported in the parent), relays rank 0's ONE JSON
+line and exits with the ranks' return code.  Launched by an external torchrun (WORLD_SIZE set) it is a rank.
 """
 import argparse
+import contextlib
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # before the HIP runtime starts (RCCL needs dmabuf IPC here)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-import _paths  # noqa: E402,F401
 
-from fbgemm_gpu import _lib  # noqa: E402
-from torchrec_amd.datasets.random import (CRITEO_1TB_ROWS, DEFAULT_CAT_NAMES, INT_FEATURE_COUNT,  # noqa: E402
-                                          RandomRecDataset)
-from torchrec_amd.distributed.embeddingbag import EmbeddingBagCollectionSharder  # noqa: E402
-from torchrec_amd.distributed.model_parallel import DistributedModelParallel  # noqa: E402
-from torchrec_amd.distributed.train_pipeline import TrainPipelineSparseDist  # noqa: E402
-from torchrec_amd.distributed.types import ShardingEnv  # noqa: E402
-from torchrec_amd.models.dlrm import DLRMTrain  # noqa: E402
-from torchrec_amd.modules.embedding_configs import EmbeddingBagConfig  # noqa: E402
-from torchrec_amd.modules.embedding_modules import EmbeddingBagCollection  # noqa: E402
-from torchrec_amd.optim.keyed import CombinedOptimizer, KeyedOptimizerWrapper  # noqa: E402
-
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured copy rate
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured copy rate
+MFMA_F32_PEAK_TFLOPS = 157.3  # fp32 matrix peak (MI355X_MICROARCH.md)
+XGMI_LINK_GBS = 153.0     # one xGMI link, one direction; 7 links per GPU
 D = 128
-F = len(CRITEO_1TB_ROWS)
+CRITEO_F = 26
+F = CRITEO_F
 # SURVEY.md §8(d) algorithmic bytes per sample (fp32 rows, int64 indices/offsets, L = 1)
 BYTES_FWD = F * (D * 4 + 8) + F * 8 + F * D * 4          # 27 040
 BYTES_BWD_SGD = F * D * 4 + F * 16 + 2 * F * D * 4       # 40 352
-
-
-import contextlib  # noqa: E402
+MFLOP_PER_SAMPLE_TRAIN = 14.75                           # SURVEY.md §8(d): 4.917 MFLOP forward x 3
 
 
 @contextlib.contextmanager
@@ -81,9 +70,12 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--num-batches", type=int, default=16, help="distinct pre-generated batches")
-    ap.add_argument("--row-wise", type=int, default=0,
-                    help="force the N largest tables row-wise (BASELINE config 3's mixed table-wise + row-wise plan); "
-                         "default 0 = the planner's own choice, which shards row-wise only for capacity")
+    ap.add_argument("--row-wise", type=int, default=-1,
+                    help="shard the N largest tables row-wise.  Default (-1): at N > 1 the pinned mixed plan of BASELINE "
+                         "config 3 / SURVEY.md §8d (the 4 largest tables row-wise, the rest table-wise or replicated), "
+                         "at N = 1 none.  0 = the planner's own choice (row-wise only for capacity)")
+    ap.add_argument("--spawn", action="store_true",
+                    help="start the rank processes through the built-in launcher even for --gpus 1")
     ap.add_argument("--tuned-gemms", choices=["on", "off"], default="on",
                     help="replay the recorded hipBLASLt / rocBLAS kernel choice per GEMM shape (torchrec_amd/tuning)")
     ap.add_argument("--hip-graphs", choices=["auto", "on", "off"], default="auto",
@@ -92,14 +84,94 @@ def parse():
     return ap.parse_args()
 
 
+def _free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(args) -> int:
+    """Parent of an N-rank run: starts N fresh rank processes (one per GPU) and relays rank 0's JSON line.
+    Nothing in this process has imported torch or touched the GPU."""
+    port = int(os.environ.get("MASTER_PORT") or _free_port())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)]
+    cmd += [a for a in sys.argv[1:] if a != "--spawn"]
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env["MASTER_ADDR"], env["MASTER_PORT"] = "127.0.0.1", str(port)
+    env["TORCHREC_AMD_BENCH_LAUNCHER"] = "bench.py"
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)  # stderr: inherited
+    line = None
+    for raw in proc.stdout:
+        txt = raw.strip()
+        if txt.startswith("{") and '"metric"' in txt:
+            line = txt  # rank 0's result; anything else a rank printed goes to stderr
+        else:
+            sys.stderr.write(raw)
+    rc = proc.wait()
+    if rc == 0 and line is None:
+        print("[bench] the ranks exited 0 but printed no result line", file=sys.stderr)
+        return 1
+    if line is not None and rc == 0:
+        print(line, flush=True)
+    return rc
+
+
+def dry_run(args) -> None:
+    """TORCHREC_AMD_BENCH_DRYRUN=1: the launcher / rendezvous / timing / reporting skeleton of a rank on CPU
+    over gloo, no model and no GPU (tests/test_bench_launcher.py drives it at N = 2).  =fail: rank 1 exits 3."""
+    import torch
+    import torch.distributed as dist
+
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if os.environ.get("TORCHREC_AMD_BENCH_DRYRUN") == "fail" and rank == world - 1:
+        sys.exit(3)
+    x = torch.ones(4)
+    for _ in range(args.warmup):
+        dist.all_reduce(x)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dist.all_reduce(x)
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "samples/sec Criteo-1TB DLRM batch 65536", "dry_run": True, "n_gpus": world,
+                          "ranks": dist.get_world_size(), "backend": dist.get_backend(), "steps": args.steps,
+                          "warmup": args.warmup, "value": args.global_batch * args.steps / float(t.item()),
+                          "launcher": os.environ.get("TORCHREC_AMD_BENCH_LAUNCHER", "external")}), flush=True)
+    dist.destroy_process_group()
+
+
 def read_profile(lib, slot):
     tot, n = ctypes.c_double(0.0), ctypes.c_int64(0)
     lib.tbe_profile_read(slot, ctypes.byref(tot), ctypes.byref(n))
     return tot.value, n.value
 
 
-def main():
-    args = parse()
+def main(args):
+    import torch
+    import torch.distributed as dist
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _paths  # noqa: F401
+    from fbgemm_gpu import _lib
+    from torchrec_amd.datasets.random import CRITEO_1TB_ROWS, DEFAULT_CAT_NAMES, INT_FEATURE_COUNT, RandomRecDataset
+    from torchrec_amd.distributed.embeddingbag import EmbeddingBagCollectionSharder
+    from torchrec_amd.distributed.model_parallel import DistributedModelParallel
+    from torchrec_amd.distributed.train_pipeline import TrainPipelineSparseDist
+    from torchrec_amd.distributed.types import ShardingEnv
+    from torchrec_amd.models.dlrm import DLRMTrain
+    from torchrec_amd.modules.embedding_configs import EmbeddingBagConfig
+    from torchrec_amd.modules.embedding_modules import EmbeddingBagCollection
+    from torchrec_amd.optim.keyed import CombinedOptimizer, KeyedOptimizerWrapper
+
+    assert len(CRITEO_1TB_ROWS) == F
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -141,12 +213,23 @@ def main():
                             dense_arch_layer_sizes=[512, 256, 128],
                             over_arch_layer_sizes=[1024, 1024, 512, 256, 1], dense_device=dev)
     hip_graphs = args.hip_graphs == "on" or (args.hip_graphs == "auto" and B_local <= 32768)
+    graphs_note = ("on" if hip_graphs else
+                   ("off by request" if args.hip_graphs == "off" else
+                    "off: per-rank batch > 32768, the GPU is busy 99 % of the step when eager (DESIGN.md §3c)"))
     from torchrec_amd.distributed.planner import EmbeddingShardingPlanner, Topology
+
+    # plan: BASELINE config 3 is MIXED table-wise + row-wise; SURVEY.md §8d pins "the 4 largest tables row-wise,
+    # 22 table-wise" so that runs are comparable.  That is the default at N > 1 (the planner's own choice would
+    # shard row-wise only for capacity, i.e. not at all here: DESIGN.md §4).
+    if args.row_wise >= 0:
+        num_rw = args.row_wise
+    else:
+        num_rw = 4 if env.world_size > 1 else 0
 
     model = DistributedModelParallel(
         module=train_model, env=env, device=dev,
         sharders=[EmbeddingBagCollectionSharder(fused_params={"learning_rate": args.lr})],
-        planner=EmbeddingShardingPlanner(Topology(env.world_size), num_row_wise=args.row_wise or None),
+        planner=EmbeddingShardingPlanner(Topology(env.world_size), num_row_wise=num_rw or None),
         init_data_parallel=False)
     if hip_graphs:
         # HIP-graph replay of the collective-free dense segments; captured before DistributedDataParallel
@@ -158,6 +241,7 @@ def main():
                                            process_group=env.process_group)
         except Exception as e:  # measured run must not die on a capture problem: run the segments eagerly
             print(f"[bench] HIP-graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr, flush=True)
+            graphs_note = f"FELL BACK to eager: capture failed with {type(e).__name__}: {str(e)[:200]}"
             train_model._graphs = None
             if hasattr(train_model, "_flat_dense"):
                 object.__delattr__(train_model, "_flat_dense")
@@ -248,7 +332,9 @@ def main():
         # PMC traffic (FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction) measured by a separate rocprofv3
         # --pmc run of the same kernels (profiles/r01_pmc_traffic.json); only valid for the N = 1 shape.
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        if not os.path.exists(pmc_path):
+            pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if world == 1 and args.global_batch == 65536 and not args.zipf and os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))
             hit = [v for k, v in pmc.items() if dom.split("(")[0] in k]
@@ -256,6 +342,9 @@ def main():
                 traffic = hit[0]["hbm_total_MB"] * 1e6
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(kern[dom]["GB/s"], 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(kern[dom]["GB/s"] / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "traffic_source": (f"profiles/{os.path.basename(pmc_path)}: separate rocprofv3 --pmc passes of the same "
+                                       "kernels at this shape (FETCH_SIZE x 2 + WRITE_SIZE), not collected in this run"
+                                       if traffic is not None else None),
                     "avg_launch_us": round(kern[dom]["avg_us"], 1),
                     "distinct_rows_per_sample": round(U_launch / args.global_batch, 2),
                     "bwd_MB_if_all_rows_distinct": round(bwd_bytes_all_distinct / 1e6, 1),
@@ -265,14 +354,47 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.ebc_torch import time_cpu_baseline
 
-        r = time_cpu_baseline(CRITEO_1TB_ROWS, D, batch=4096, seconds_budget=args.cpu_seconds)
-        cpu = {"value": round(r["train_samples_per_s"], 1), "unit": "samples/s", "cores": r["cores"], "kind": "port",
-               "fwd_only_value": round(r["fwd_samples_per_s"], 1),
+        r = time_cpu_baseline(CRITEO_1TB_ROWS, D, batches=tuple(dict.fromkeys((4096, args.global_batch))),
+                              seconds_budget=args.cpu_seconds)
+        big, small = r["per_batch"][args.global_batch], r["per_batch"][4096]
+        cap_txt = f"tables capped at {r['row_cap']} rows (host RAM < 100 GB)" if r["row_cap"] else "full-size tables (84.85 GiB in host memory)"
+        cpu = {"value": round(big["train_samples_per_s"], 1), "unit": "samples/s", "cores": r["cores"], "kind": "port",
+               "fwd_only_value": round(big["fwd_samples_per_s"], 1),
+               "batch_4096": {"value": round(small["train_samples_per_s"], 1),
+                              "fwd_only_value": round(small["fwd_samples_per_s"], 1)},
                "sample": (f"reference EmbeddingBagCollection design (26 x nn.EmbeddingBag sum, sparse=True + SGD; "
-                          f"embedding part only, no MLPs) batch {r['batch']}, tables capped at {r['row_cap']} rows, "
-                          f"{r['train_iters']} train + {r['fwd_iters']} fwd iterations")}
+                          f"embedding part only, no MLPs), {cap_txt}, batch {args.global_batch}: "
+                          f"{big['train_iters']} train + {big['fwd_iters']} fwd iterations, batch 4096: "
+                          f"{small['train_iters']} + {small['fwd_iters']}; tables built in {r['build_s']:.1f} s (untimed)")}
+
+    # ---- whole-step fractions and the binding resource (model-based, per rank) ------------------------
+    # end to end: algorithmic embedding bytes per sample x samples/s over W x HBM peak, and the
+    # dense side's 14.75 MFLOP per sample over W x the fp32 MFMA peak
+    end_to_end = {
+        "hbm_frac": round((BYTES_FWD + BYTES_BWD_SGD) * value / (world * HBM_PEAK_GBS * 1e9), 4),
+        "hbm_bytes_per_sample": BYTES_FWD + BYTES_BWD_SGD,
+        "mfma_f32_frac": round(MFLOP_PER_SAMPLE_TRAIN * 1e6 * value / (world * MFMA_F32_PEAK_TFLOPS * 1e12), 4),
+        "mflop_per_sample": MFLOP_PER_SAMPLE_TRAIN,
+    }
+    n_tw_per_rank = [sum(1 for i in range(F) if kind[i] == r) for r in range(world)]
+    n_rw_feats = sum(1 for i in range(F) if kind[i] == -1)
+    # pooled all-to-all: a rank sends [B_local, D] per feature it holds (row-wise features: every rank holds a
+    # shard) to EACH peer over that peer's own link, forward; the same volume comes back as gradients
+    link_bytes = B_local * D * 4 * (max(n_tw_per_rank) + n_rw_feats) if world > 1 else 0
+    xgmi_bytes_rank = 2 * (world - 1) * B_local * D * 4 * (n_tw_per_rank[rank] + n_rw_feats) if world > 1 else 0
+    ids_bytes_rank = (world - 1) * B_local * 8 * (F - n_dp) // max(world, 1) + (world - 1) * B_local * 8 * n_rw_feats if world > 1 else 0
+    est_ms = {
+        "mfma_f32": B_local * MFLOP_PER_SAMPLE_TRAIN * 1e6 / (MFMA_F32_PEAK_TFLOPS * 1e12) * 1e3,
+        "hbm_embedding": (fwd_bytes + bwd_bytes) / (HBM_PEAK_GBS * 1e9) * 1e3,
+        "xgmi_busiest_link": 2 * link_bytes / (XGMI_LINK_GBS * 1e9) * 1e3,
+    }
+    binding = {"resource": max(est_ms, key=est_ms.get), "est_ms_per_step_at_peak": {k: round(v, 3) for k, v in est_ms.items()},
+               "xgmi_bytes_per_rank_per_step": int(xgmi_bytes_rank + 2 * ids_bytes_rank),
+               "note": "time each resource would need at its peak rate for this rank's share of one step; the largest binds"}
 
     if rank == 0:
+        if roofline is not None:
+            roofline["end_to_end"] = end_to_end
         out = {
             "metric": "samples/sec Criteo-1TB DLRM batch 65536", "value": round(value, 1), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -280,14 +402,22 @@ def main():
             # the reference's only published number is 5 497 159.68 samples/s on 8 x A100-40GB
             # (examples/dlrm/README.MD:45, real Criteo data, end to end) — comparable at N = 8 only
             "vs_baseline": round(value / 5497159.68, 3) if world == 8 else None,
-            "dtype": "f32", "data": "synthetic", "hip_graphs": hip_graphs, "tuned_gemms": tuned,
+            "dtype": "f32", "data": "synthetic", "hip_graphs": hip_graphs, "hip_graphs_note": graphs_note,
+            "tuned_gemms": tuned,
+            "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 0,
+            "backend": dist.get_backend() if dist.is_initialized() else None,
+            "launcher": os.environ.get("TORCHREC_AMD_BENCH_LAUNCHER", "external torchrun" if world > 1 else "direct"),
             "config": {"workload": "DLRM Criteo-1TB shape: 26 tables (177.9M rows, 84.85 GiB fp32, D=128), 13 dense, "
                                    "pooling factor 1, dense 512-256-128, over 1024-1024-512-256-1, fused exact SGD",
                        "global_batch": args.global_batch, "local_batch": B_local,
                        "parallelism": (f"mp{world}: {F - n_rw - n_dp} table-wise + {n_rw} row-wise + {n_dp} replicated "
                                        f"(data-parallel) tables, dense dp{world}"),
+                       "plan": {"table_wise": F - n_rw - n_dp, "row_wise": n_rw, "data_parallel": n_dp,
+                                "table_wise_per_rank": n_tw_per_rank, "row_wise_arg": args.row_wise,
+                                "source": ("pinned mixed plan (BASELINE config 3, SURVEY.md §8d)" if args.row_wise < 0 and world > 1
+                                           else "torchrec_amd planner" if args.row_wise <= 0 else "--row-wise")},
                        "ids": f"zipf({args.zipf})" if args.zipf else "uniform", "row_cap": args.row_cap or None},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "binding": binding, "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
@@ -295,4 +425,10 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    _args = parse()
+    if "WORLD_SIZE" not in os.environ and (_args.gpus > 1 or _args.spawn):
+        sys.exit(launch_ranks(_args))  # before torch is imported: the parent never touches the GPU
+    if os.environ.get("TORCHREC_AMD_BENCH_DRYRUN"):
+        dry_run(_args)
+    else:
+        main(_args)

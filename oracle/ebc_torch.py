@@ -36,35 +36,64 @@ class RefEmbeddingBagCollection(nn.Module):
         return torch.cat(pooled, dim=1)
 
 
-def time_cpu_baseline(rows: List[int], dim: int, batch: int, seconds_budget: float = 20.0, row_cap: int = 1 << 20,
-                      seed: int = 1234):
-    """Times forward and forward+backward+SGD of the reference design on the host cores with the
-    same id distribution as the GPU run (uniform, pooling factor 1).  Tables are capped at
-    `row_cap` rows so that initialisation stays bounded; returns a dict for bench.py."""
+def default_row_cap() -> int:
+    """SURVEY.md §8d / BASELINE.md §3: tables are capped at 4 M rows only if the host has < ~100 GB of RAM
+    (0 = no cap: the full 84.85 GiB of tables in host memory)."""
+    try:
+        import psutil
+
+        total = psutil.virtual_memory().total
+    except Exception:  # no psutil: be safe
+        return 4 << 20
+    return 0 if total >= 100e9 else 4 << 20
+
+
+def time_cpu_baseline(rows: List[int], dim: int, batches=(4096, 65536), seconds_budget: float = 24.0,
+                      row_cap: Optional[int] = None, seed: int = 1234):
+    """Times forward and forward+backward+SGD of the reference design on the host cores with the same id
+    distribution as the GPU run (uniform, pooling factor 1), at every batch size in `batches` (one model,
+    built once).  `row_cap`: None = default_row_cap(), 0 = full tables.  Tables are filled with a constant
+    (every page is written once, so lookups touch real memory; the values do not matter for timing).
+    Returns {"cores", "row_cap", "build_s", "per_batch": {batch: {...}}}."""
     g = torch.Generator()
     g.manual_seed(seed)
-    capped = [min(r, row_cap) for r in rows]
+    if row_cap is None:
+        row_cap = default_row_cap()
+    capped = [min(r, row_cap) if row_cap else r for r in rows]
     F = len(rows)
-    ebc = RefEmbeddingBagCollection(capped, [dim] * F, sparse=True)
-    values = torch.cat([torch.randint(0, r, (batch,), generator=g) for r in capped])
-    offsets = torch.arange(F * batch + 1)
+    t0 = time.perf_counter()
+    ebc = RefEmbeddingBagCollection.__new__(RefEmbeddingBagCollection)
+    nn.Module.__init__(ebc)
+    ebc.F = F
+    bags = {}
+    for i, r in enumerate(capped):
+        w = torch.empty(r, dim)
+        w.fill_(0.01)
+        bags[f"t{i}"] = nn.EmbeddingBag(num_embeddings=r, embedding_dim=dim, mode="sum", include_last_offset=True,
+                                        sparse=True, _weight=w)
+    ebc.embedding_bags = nn.ModuleDict(bags)
+    build_s = time.perf_counter() - t0
     opt = torch.optim.SGD(ebc.parameters(), lr=0.01)
-    ebc(values, offsets)  # warm-up
-    t0, n_f = time.perf_counter(), 0
-    with torch.no_grad():
-        while time.perf_counter() - t0 < seconds_budget / 3 or n_f < 2:
-            ebc(values, offsets)
-            n_f += 1
-    fwd_s = (time.perf_counter() - t0) / n_f
-    grad = torch.randn(batch, F * dim, generator=g)
-    t0, n_t = time.perf_counter(), 0
-    while time.perf_counter() - t0 < seconds_budget * 2 / 3 or n_t < 2:
-        opt.zero_grad()
-        ebc(values, offsets).backward(grad)
-        opt.step()
-        n_t += 1
-    train_s = (time.perf_counter() - t0) / n_t
-    return {
-        "fwd_samples_per_s": batch / fwd_s, "train_samples_per_s": batch / train_s,
-        "cores": torch.get_num_threads(), "batch": batch, "row_cap": row_cap, "fwd_iters": n_f, "train_iters": n_t,
-    }
+    per_batch = {}
+    share = seconds_budget / max(len(batches), 1)
+    for batch in batches:
+        values = torch.cat([torch.randint(0, r, (batch,), generator=g) for r in capped])
+        offsets = torch.arange(F * batch + 1)
+        ebc(values, offsets)  # warm-up
+        t0, n_f = time.perf_counter(), 0
+        with torch.no_grad():
+            while time.perf_counter() - t0 < share / 3 or n_f < 2:
+                ebc(values, offsets)
+                n_f += 1
+        fwd_s = (time.perf_counter() - t0) / n_f
+        grad = torch.randn(batch, F * dim, generator=g)
+        t0, n_t = time.perf_counter(), 0
+        while time.perf_counter() - t0 < share * 2 / 3 or n_t < 2:
+            opt.zero_grad()
+            ebc(values, offsets).backward(grad)
+            opt.step()
+            n_t += 1
+        train_s = (time.perf_counter() - t0) / n_t
+        per_batch[batch] = {"fwd_samples_per_s": batch / fwd_s, "train_samples_per_s": batch / train_s,
+                            "fwd_iters": n_f, "train_iters": n_t}
+    return {"cores": torch.get_num_threads(), "row_cap": row_cap, "build_s": build_s, "per_batch": per_batch}

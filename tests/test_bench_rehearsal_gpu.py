@@ -24,12 +24,18 @@ def test_bench_default_path():
     d = _run({}, "--global-batch", "4096")
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["roofline"]["bound"] == "hbm" and d["hip_graphs"] is True
     assert d["metric"].startswith("samples/sec") and d["unit"] == "samples/s" and d["scaling"] == "strong"
+    assert d["launcher"] == "direct" and d["rccl_ranks"] == 0
+    e2e = d["roofline"]["end_to_end"]
+    assert 0 < e2e["hbm_frac"] < 1 and 0 < e2e["mfma_f32_frac"] < 1 and e2e["hbm_bytes_per_sample"] == 67392
 
 
 def test_bench_one_rank_rehearsal_of_the_multi_gpu_path():
     env = {"TORCHREC_AMD_FORCE_EXCHANGE": "1", "TORCHREC_AMD_FORCE_DDP": "1", "TORCHREC_AMD_FORCE_DP": "1",
            "MASTER_PORT": "29561"}
-    d = _run(env, "--global-batch", "4096")
+    d = _run(env, "--global-batch", "4096", "--spawn")  # through bench.py's own launcher, as `--gpus N` goes
     assert "11 replicated" in d["config"]["parallelism"] and d["hip_graphs"] is True and d["value"] > 0
+    assert d["launcher"] == "bench.py" and d["rccl_ranks"] == 1 and d["backend"] == "nccl"
+    assert d["config"]["plan"]["data_parallel"] == 11 and d["hip_graphs_note"] == "on"
+    assert d["binding"]["resource"] in ("mfma_f32", "hbm_embedding", "xgmi_busiest_link")
     e = _run(env, "--global-batch", "4096", "--hip-graphs", "off", "--tuned-gemms", "off")
     assert e["hip_graphs"] is False and e["tuned_gemms"] is False and e["value"] > 0

@@ -359,7 +359,7 @@ class _TBEBase(nn.Module):
         # "auto": only for lookups small enough to leave CUs idle (measured on MI355X: at 1.7 M ids the
         # side-stream sort steals bandwidth from the GEMMs, -2 %; at 213 K ids it hides, +4 %)
         self.overlap_backward_sort = os.environ.get("TBE_OVERLAP_SORT", "auto")
-        self.overlap_backward_sort_max_ids = 1 << 20
+        self.overlap_backward_sort_max_ids = 1 << 22  # the one-launch-per-pass sort no longer steals GEMM bandwidth
 
     def __getstate__(self):
         # copy.deepcopy / pickling (model_parallel.py:294-298 deep-copies sharded modules): HIP streams
