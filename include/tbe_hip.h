@@ -57,6 +57,10 @@ extern "C" {
 #define TBE_OPT_EXACT_ADAGRAD 3
 #define TBE_OPT_DENSE_GRAD 100
 
+/* An id with this value is skipped silently by every lookup (no row, no bounds error): how the row cache hands
+ * "this row belongs to another rank's shard" to the lookup kernels. */
+#define TBE_ID_SKIP INT64_MIN
+
 #define TBE_FLAG_UNIFORM_ALIGNED 1
 #define TBE_FLAG_WEIGHTED 2 /* per_sample_weights will be / are given (backward: selects the sort payload layout) */
 
@@ -111,13 +115,20 @@ int tbe_profile_read_rows(int64_t* rows_updated);
  *                [0, rows); such an index contributes a zero row (never dereferenced).  Also incremented for
  *                every bag whose offsets are malformed (start < 0, end > N, start > end): such a bag is
  *                empty in forward and contributes nothing in backward — no memory is touched through it.
+ * feat_window    optional [2F] int64: (first global row held, global rows of the table) per feature, for
+ *                row-wise shards whose ids arrive un-bucketized (the reference bucketizes instead:
+ *                torchrec/distributed/embedding_sharding.py:121-184, sharding/rw_sharding.py:229-236).  Ids are
+ *                then GLOBAL rows: those in [first, first + feat_rows) are looked up at id - first, other
+ *                ids in [0, global rows) belong to another rank's shard and are skipped SILENTLY, ids outside
+ *                [0, global rows) count as bounds errors.  NULL = every feature holds its whole table.
+ *                The same parameter of tbe_backward_* and tbe_cache_prefetch means the same.
  * ---------------------------------------------------------------------------------- */
 int tbe_forward_pooled_f32(const uint64_t* feat_weights, const int32_t* feat_D,
                            const int64_t* feat_out_offset, const int64_t* feat_rows, int32_t F,
                            int32_t B, int32_t max_D, const int64_t* indices,
                            int64_t N, const int64_t* offsets, const float* per_sample_weights,
                            int32_t pooling_mode, float* out, int64_t out_row_stride,
-                           int32_t* bounds_errors, void* stream);
+                           int32_t* bounds_errors, const int64_t* feat_window, void* stream);
 
 /* TBE forward, PoolingMode.NONE (sequence / unpooled): out[i, :] = W_f(i)[indices[i], :]
  * with f(i) the feature whose offsets range contains i.  All features must share one
@@ -160,7 +171,7 @@ int tbe_backward_fused_f32(const uint64_t* feat_weights, const int32_t* feat_D,
                            const int64_t* offsets, const float* per_sample_weights,
                            int32_t pooling_mode, const float* grad_out,
                            int64_t grad_row_stride, tbe_optimizer_args opt, int32_t flags,
-                           void* workspace, size_t workspace_bytes, int32_t* bounds_errors,
+                           void* workspace, size_t workspace_bytes, int32_t* bounds_errors, const int64_t* feat_window,
                            void* stream);
 
 /* The backward in two phases, so that the gradient-independent half (linearize + stable sort of
@@ -173,7 +184,7 @@ int tbe_backward_fused_f32(const uint64_t* feat_weights, const int32_t* feat_D,
 int tbe_backward_prepare(const int64_t* feat_rows, const int64_t* feat_row_base, int32_t F,
                          int32_t B, int32_t max_D, int32_t key_bits, const int64_t* indices,
                          int64_t N, const int64_t* offsets, int32_t pooling_mode, int32_t flags,
-                         void* workspace, size_t workspace_bytes, int32_t* bounds_errors,
+                         void* workspace, size_t workspace_bytes, int32_t* bounds_errors, const int64_t* feat_window,
                          void* stream);
 
 /* The stable pair sort the backward and the row cache use, exposed for tests and micro-benchmarks
@@ -245,7 +256,7 @@ int tbe_cache_prefetch(const tbe_cache_desc* desc, const int32_t* feat_cached_ta
                        const int64_t* feat_rows, int32_t F, int32_t B, const int64_t* indices,
                        int64_t N, const int64_t* offsets, int32_t key_bits, int32_t iteration,
                        int64_t* remapped_indices, void* workspace, size_t workspace_bytes,
-                       void* stream);
+                       const int64_t* feat_window, void* stream);
 int tbe_cache_writeback_staging(const tbe_cache_desc* desc, void* stream);
 int tbe_cache_flush(const tbe_cache_desc* desc, int32_t invalidate, void* stream);
 

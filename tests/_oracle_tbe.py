@@ -46,6 +46,22 @@ class OracleTBE(nn.Module):
     def set_a2a_output_layout(self, W):
         self._W = W
 
+    def set_row_windows(self, first_rows, global_rows=None):
+        """Stand-in for the product's row windows: global ids -> shard-local ids (rows of other shards become -1,
+        which the oracle treats as a zero row)."""
+        self._win_first = None if first_rows is None else np.asarray(first_rows, dtype=np.int64)
+
+    def _localize(self, indices, offsets):
+        first = getattr(self, "_win_first", None)
+        if first is None:
+            return indices
+        B = (offsets.numel() - 1) // self.F
+        per_feat = (offsets[B::B] - offsets[:-1:B]).numpy()
+        shift = np.repeat(first, per_feat)
+        rows = np.repeat(np.asarray([self.tables.rows[t] for t in self.tables.ftm], dtype=np.int64), per_feat)
+        loc = indices.numpy() - shift
+        return torch.from_numpy(np.where((loc >= 0) & (loc < rows), loc, -1))
+
     def _to_layout(self, out):  # [B, W*Dl] -> [W*B, Dl]
         if not self._W:
             return out
@@ -68,7 +84,7 @@ class OracleTBE(nn.Module):
         self.optimizer_args.learning_rate = lr
 
     def forward(self, indices, offsets, psw=None):
-        return _Fn.apply(self.placeholder, self, indices.long(), offsets.long(), psw)
+        return _Fn.apply(self.placeholder, self, self._localize(indices.long(), offsets.long()), offsets.long(), psw)
 
 
 def oracle_tbe_factory(specs, ftm, pooling_mode, device, fused_params):
@@ -117,7 +133,8 @@ class _FnInto(torch.autograd.Function):
 
 
 def _fused_forward_into(self, out, out_offsets, row_stride, indices, offsets, psw=None):
-    return _FnInto.apply(out, self.placeholder, self, indices.long(), offsets.long(), psw, out_offsets.tolist(),
+    return _FnInto.apply(out, self.placeholder, self, self._localize(indices.long(), offsets.long()), offsets.long(), psw,
+                         out_offsets.tolist(),
                          int(row_stride))
 
 

@@ -147,6 +147,7 @@ def _worker(rank, W, port, fixed_len, weighted, n_rw, dp_max_rows, ret, offload=
         if offload:
             assert plan["t3"].compute_kernel == "batched_fused_uvm_caching" and sebc._emb_module._cache is not None
         ret[rank] = (out, shards, {n: p.sharding_type for n, p in plan.items()})
+        ret[f"errors{rank}"] = sebc._emb_module.bounds_check_errors() if sebc._emb_module is not None else 0
     finally:
         dist.destroy_process_group()
 
@@ -170,6 +171,9 @@ def _check_against_oracle(ret, W, fixed_len, weighted, n_rw, dp_max_rows, adagra
         else:
             np.testing.assert_allclose(ret[r][0], ref, rtol=1e-5, atol=1e-5)
     kinds = ret[0][2]
+    for r in range(W):  # every id is valid: rows held by another rank's shard must NOT count as bounds errors
+        if f"errors{r}" in ret:
+            assert ret[f"errors{r}"] == 0
     assert sum(1 for k in kinds.values() if k == "row_wise") == n_rw
     assert sum(1 for k in kinds.values() if k == "data_parallel") == (sum(1 for r in ROWS if r <= dp_max_rows) if W > 1 else 0)
     g_len = np.concatenate([np.concatenate([per_rank[r][0][f * B:(f + 1) * B] for r in range(W)]) for f in range(F)])
@@ -261,6 +265,75 @@ def test_sharded_world2_with_host_offloaded_tables():
     ret = ResultStore()
     mp.spawn(_worker, args=(W, _free_port(), 2, False, 1, 10, ret, True), nprocs=W, join=True)
     _check_against_oracle(ret, W, 2, False, 1, 10)
+
+
+def _bad_id_worker(rank, W, port, offload, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=W)
+    try:
+        _stage_a2a_through_host()
+        from torchrec_amd.distributed.types import ShardingEnv
+        from torchrec_amd.sparse.jagged_tensor import KeyedJaggedTensor
+
+        per_rank, init = _data(W, 1, False)
+        keys, plan, sebc = _build_sharded(W, ShardingEnv.from_process_group(dist.group.WORLD), False, 2, 0, offload)
+        dev = torch.device("cuda", 0)
+        for name, (w, row0) in sebc.local_shards().items():
+            w.copy_(torch.from_numpy(init[int(name[1:])][row0:row0 + w.shape[0]]))
+        vals = _inject_bad_ids(per_rank[rank][1].copy(), plan, rank)
+        kjt = KeyedJaggedTensor.from_fixed_lengths(keys, torch.from_numpy(vals).to(dev), [1] * len(keys))
+        with torch.no_grad():  # forward only: the backward's linearize would count the same ids a second time
+            out = sebc(kjt).wait().values()
+        torch.cuda.synchronize()
+        ret[rank] = (out.detach().cpu().numpy().copy(), {n: (p.sharding_type, p.ranks) for n, p in plan.items()})
+        ret[f"errors{rank}"] = sebc._emb_module.bounds_check_errors()
+    finally:
+        dist.destroy_process_group()
+
+
+def _inject_bad_ids(vals, plan, rank):
+    """Rank r's batch gets, in EVERY feature, one id just past the table (sample 3 + r) and one negative id
+    (sample 7 + r)."""
+    for f in range(len(ROWS)):
+        vals[f * B_LOCAL + 3 + rank] = ROWS[f] + rank
+        vals[f * B_LOCAL + 7 + rank] = -1 - rank
+    return vals
+
+
+@pytest.mark.parametrize("offload", [False, True])
+def test_row_wise_shards_report_exactly_the_truly_out_of_range_ids(offload):
+    """Two ranks, two row-wise tables (one behind the HBM row cache when offload) + table-wise ones.  Every rank
+    sees every id of a row-wise feature: rows of the other rank's shard are skipped SILENTLY, ids outside
+    [0, global rows) are counted by every rank that sees them; a table-wise feature's bad ids are counted by its
+    owner only.  Outputs equal the oracle's (a bad id contributes a zero row).  Reference contract:
+    embedding_sharding.py:121-184 + rw_sharding.py:229-236 (bucketize, so foreign rows never arrive)."""
+    from oracle import oracle
+
+    W = 2
+    ret = ResultStore()
+    mp.spawn(_bad_id_worker, args=(W, _free_port(), offload, ret), nprocs=W, join=True)
+    per_rank, init = _data(W, 1, False)
+    F = len(ROWS)
+    tabs = oracle.Tables(ROWS, [D] * F)
+    for t in range(F):
+        tabs.weights[t][...] = init[t]
+    plan = ret[0][1]
+    for r in range(W):
+        vals = _inject_bad_ids(per_rank[r][1].copy(), plan, r)
+        ref, nbad = oracle.tbe_forward(tabs, vals, np.arange(F * B_LOCAL + 1, dtype=np.int64), None, oracle.POOL_SUM)
+        assert nbad == 2 * F
+        np.testing.assert_array_equal(ret[r][0], ref)
+    for r in range(W):
+        expect = 0
+        for f in range(F):
+            kind, ranks = plan[f"t{f}"]
+            if kind == "row_wise":
+                expect += 2 * W  # both ranks' two bad ids reach this rank
+            elif kind == "table_wise" and ranks[0] == r:
+                expect += 2 * W  # the owner sees both ranks' batches
+        assert ret[f"errors{r}"] == expect, (r, ret[f"errors{r}"], expect)
 
 
 @pytest.mark.parametrize("fixed_len,weighted,dp_max_rows", [(1, False, 10), (0, True, 0)])

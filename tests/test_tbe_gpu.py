@@ -448,3 +448,75 @@ def test_malformed_offsets_never_reach_memory():
         keep = np.array([r not in ambiguous[t] for r in range(rows[t])])
         np.testing.assert_allclose(w.cpu().numpy()[keep], (exp[t] - 0.5 * acc[t])[keep], rtol=1e-5, atol=1e-5)
         assert np.isfinite(w.cpu().numpy()).all()
+
+
+def test_row_window_skips_other_shards_rows_silently_and_counts_real_errors():
+    """`set_row_windows`: a shard of 40 rows holding global rows [100, 140) of a 300-row table, fed with GLOBAL
+    ids: in-window ids are looked up at id - 100, other ids of the table are skipped without a bounds error,
+    ids outside [0, 300) are counted.  Forward and backward (fused SGD), pooled SUM with ragged bags."""
+    rng = np.random.default_rng(77)
+    rows, dims = [40, 50], [64, 64]
+    mod, tabs = build_pair(rows, dims, None, 0, rng=rng, learning_rate=0.25)
+    mod.set_row_windows([100, 0], [300, 50])
+    B = 33
+    lengths = rng.integers(0, 4, size=2 * B)
+    n0, n1 = int(lengths[:B].sum()), int(lengths[B:].sum())
+    ids0 = rng.integers(0, 300, size=n0)
+    in_win = rng.random(n0) < 0.4
+    ids0 = np.where(in_win, rng.integers(100, 140, size=n0), ids0)
+    ids1 = rng.integers(0, 50, size=n1)
+    bad0, bad1 = [300, 1000, -1, -7], [50, -2]
+    ids0[:len(bad0)] = bad0
+    ids1[:len(bad1)] = bad1
+    indices = np.concatenate([ids0, ids1]).astype(np.int64)
+    offsets = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+    before = mod.bounds_check_errors()
+    with torch.no_grad():
+        mod(to_dev(indices), to_dev(offsets))
+    assert mod.bounds_check_errors() - before == len(bad0) + len(bad1)
+    out = mod(to_dev(indices), to_dev(offsets))
+    # expectation: the oracle on shard-local ids, rows of other shards / bad ids -> -1 (zero row)
+    local = indices.copy()
+    loc0 = ids0 - 100
+    local[:n0] = np.where((loc0 >= 0) & (loc0 < 40), loc0, -1)
+    local[n0:] = np.where((ids1 >= 0) & (ids1 < 50), ids1, -1)
+    ref, _ = oracle.tbe_forward(tabs, local, offsets)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref, rtol=1e-6, atol=1e-6)
+    g = rng.standard_normal(ref.shape).astype(np.float32)
+    out.backward(to_dev(g))
+    torch.cuda.synchronize()
+    oracle.tbe_backward(tabs, local, offsets, g, oracle.OPT_EXACT_SGD, 0.25)
+    for t, w in enumerate(mod.split_embedding_weights()):
+        np.testing.assert_allclose(w.cpu().numpy(), tabs.weights[t], rtol=2e-5, atol=2e-5)
+    # the training forward and the backward's linearize each counted the same ids once more
+    assert mod.bounds_check_errors() - before == 3 * (len(bad0) + len(bad1))
+
+
+def test_bounds_check_modes():
+    """BoundsCheckMode (public fbgemm enum; parity unpinned): WARNING counts, FATAL raises after
+    the lookup, IGNORE / NONE do not count — an out-of-range id is a zero row in every mode."""
+    from fbgemm_gpu.split_table_batched_embeddings_ops import (
+        BoundsCheckMode, ComputeDevice, EmbeddingLocation, SplitTableBatchedEmbeddingBagsCodegen)
+
+    dev = torch.device("cuda", 0)
+    idx = torch.tensor([1, 99, 2, -5], dtype=torch.int64, device=dev)
+    off = torch.arange(5, dtype=torch.int64, device=dev)
+
+    def make(mode):
+        m = SplitTableBatchedEmbeddingBagsCodegen([(10, 8, EmbeddingLocation.DEVICE, ComputeDevice.CUDA)], device=dev,
+                                                  bounds_check_mode=mode)
+        m.split_embedding_weights()[0].fill_(1.0)
+        return m
+
+    with torch.no_grad():
+        m = make(BoundsCheckMode.WARNING)
+        out = m(idx, off)
+        assert m.bounds_check_errors() == 2 and out.sum().item() == 16.0
+        for mode in (BoundsCheckMode.IGNORE, BoundsCheckMode.NONE):
+            m = make(mode)
+            out = m(idx, off)
+            assert m.bounds_check_errors() == 0 and out.sum().item() == 16.0
+        m = make(BoundsCheckMode.FATAL)
+        with pytest.raises(RuntimeError, match="BoundsCheckMode.FATAL: 2 out-of-range"):
+            m(idx, off)
+        assert m(torch.tensor([1, 2, 3, 4], dtype=torch.int64, device=dev), off).sum().item() == 32.0  # valid lookups go on

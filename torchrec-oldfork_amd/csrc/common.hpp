@@ -67,6 +67,29 @@ struct Carver {
   size_t total() const { return align_up(used, 256); }
 };
 
+// Row ownership of a feature's table shard (row-wise sharding without a bucketize pass: every rank sees every
+// id of the feature).  With a window the ids are GLOBAL rows of the table and the shard holds
+// [lo, lo + rows); without one (feat_window == nullptr) lo = 0 and global_rows = rows.
+struct RowWindow {
+  int64_t lo, rows, global_rows;
+};
+__device__ __forceinline__ RowWindow load_window(const int64_t* feat_rows, const int64_t* feat_window, int f) {
+  RowWindow w;
+  w.rows = feat_rows[f];
+  w.lo = feat_window != nullptr ? feat_window[2 * f] : 0;
+  w.global_rows = feat_window != nullptr ? feat_window[2 * f + 1] : w.rows;
+  return w;
+}
+constexpr int kIdLocal = 0;    // a row of this shard: `local` = id - lo
+constexpr int kIdForeign = 1;  // another shard's row, or TBE_ID_SKIP: contributes nothing, silently
+constexpr int kIdBad = 2;      // outside [0, global_rows): contributes nothing and is counted in bounds_errors
+__device__ __forceinline__ int classify_id(const RowWindow& w, int64_t id, int64_t& local) {
+  local = static_cast<int64_t>(static_cast<uint64_t>(id) - static_cast<uint64_t>(w.lo));
+  if (static_cast<uint64_t>(local) < static_cast<uint64_t>(w.rows)) return kIdLocal;
+  if (id == TBE_ID_SKIP || static_cast<uint64_t>(id) < static_cast<uint64_t>(w.global_rows)) return kIdForeign;
+  return kIdBad;
+}
+
 // Broadcast lane `src` (0..63) of a 64-bit value.
 __device__ __forceinline__ int64_t shfl64(int64_t v, int src) {
   int lo = __shfl(static_cast<int>(v & 0xffffffffll), src, kWave);

@@ -39,6 +39,7 @@ struct BwdArgs {
   const int64_t* feat_out_offset;
   const int64_t* feat_rows;
   const int64_t* feat_row_base;
+  const int64_t* feat_window;
   const uint64_t* feat_state0;
   const uint64_t* feat_state1;
   const int64_t* indices;
@@ -98,7 +99,8 @@ __device__ __forceinline__ uint32_t payload_pos(PayT p) {
 template <typename KeyT, typename PayT>
 __global__ __launch_bounds__(256) void bwd_linearize_pooled_kernel(
     const int64_t* __restrict__ indices, const int64_t* __restrict__ offsets,
-    const int64_t* __restrict__ feat_rows, const int64_t* __restrict__ feat_row_base, int F, int B,
+    const int64_t* __restrict__ feat_rows, const int64_t* __restrict__ feat_row_base,
+    const int64_t* __restrict__ feat_window, int F, int B,
     int64_t N, int key_bits, KeyT* __restrict__ keys, PayT* __restrict__ payload,
     int32_t* bounds_errors) {
   const int64_t bag = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -112,15 +114,15 @@ __global__ __launch_bounds__(256) void bwd_linearize_pooled_kernel(
     if (bounds_errors != nullptr) atomicAdd(bounds_errors, 1);
     return;
   }
-  const int64_t rows = feat_rows[f];
+  const RowWindow win = load_window(feat_rows, feat_window, f);
   const int64_t base = feat_row_base[f];
   const KeyT sentinel = static_cast<KeyT>((key_bits >= 64) ? ~0ull : ((1ull << key_bits) - 1ull));
   int nbad = 0;
   for (int64_t p = s; p < e; ++p) {
-    const int64_t idx = indices[p];
-    const bool ok = static_cast<uint64_t>(idx) < static_cast<uint64_t>(rows);
-    if (!ok) ++nbad;
-    keys[p] = ok ? static_cast<KeyT>(base + idx) : sentinel;
+    int64_t lidx;
+    const int cls = classify_id(win, indices[p], lidx);  // rows of other shards: no key, not an error
+    if (cls == kIdBad) ++nbad;
+    keys[p] = cls == kIdLocal ? static_cast<KeyT>(base + lidx) : sentinel;
     payload[p] = make_payload<PayT>(static_cast<uint32_t>(bag), static_cast<uint32_t>(p));
   }
   if (nbad > 0 && bounds_errors != nullptr) atomicAdd(bounds_errors, nbad);
@@ -760,7 +762,7 @@ static int run_backward(BwdArgs a, const BwdWorkspace& w, int32_t max_D, hipStre
       const int64_t nbags = static_cast<int64_t>(a.F) * a.B;
       const unsigned grid = static_cast<unsigned>((nbags + 255) / 256);
       hipLaunchKernelGGL((bwd_linearize_pooled_kernel<KeyT, PayT>), dim3(grid), dim3(256), 0, st, a.indices, a.offsets,
-                         a.feat_rows, a.feat_row_base, a.F, a.B, a.N, a.key_bits, kin, pin, a.bounds_errors);
+                         a.feat_rows, a.feat_row_base, a.feat_window, a.F, a.B, a.N, a.key_bits, kin, pin, a.bounds_errors);
     }
     TBE_CHECK_LAUNCH("tbe_backward linearize");
     const int where = radix_sort_pairs<KeyT, PayT>(kin, kout, pin, pout, a.N, a.key_bits, w.sort, st, kSortStateZeroed);
@@ -796,7 +798,7 @@ static int backward_entry(
     int32_t key_bits, const int64_t* indices, int64_t N, const int64_t* offsets,
     const float* per_sample_weights, int32_t pooling_mode, const float* grad_out,
     int64_t grad_row_stride, tbe_optimizer_args opt, int32_t flags, void* workspace,
-    size_t workspace_bytes, int32_t* bounds_errors, void* stream, int phase) {
+    size_t workspace_bytes, int32_t* bounds_errors, const int64_t* feat_window, void* stream, int phase) {
   TBE_REQUIRE(F > 0 && B >= 0 && N >= 0, "tbe_backward_fused_f32: bad sizes");
   if (phase == kPhasePrepare) {  // gradient / optimizer arguments are not used by this phase
     grad_row_stride = 1;
@@ -847,6 +849,7 @@ static int backward_entry(
   a.feat_out_offset = feat_out_offset;
   a.feat_rows = feat_rows;
   a.feat_row_base = feat_row_base;
+  a.feat_window = feat_window;
   a.feat_state0 = feat_state0;
   a.feat_state1 = feat_state1;
   a.indices = indices;
@@ -892,21 +895,22 @@ extern "C" int tbe_backward_fused_f32(
     int32_t key_bits, const int64_t* indices, int64_t N, const int64_t* offsets,
     const float* per_sample_weights, int32_t pooling_mode, const float* grad_out,
     int64_t grad_row_stride, tbe_optimizer_args opt, int32_t flags, void* workspace,
-    size_t workspace_bytes, int32_t* bounds_errors, void* stream) {
+    size_t workspace_bytes, int32_t* bounds_errors, const int64_t* feat_window, void* stream) {
   return backward_entry(feat_weights, feat_D, feat_out_offset, feat_rows, feat_row_base, feat_state0, feat_state1, F,
                         B, max_D, key_bits, indices, N, offsets, per_sample_weights, pooling_mode, grad_out,
-                        grad_row_stride, opt, flags, workspace, workspace_bytes, bounds_errors, stream,
+                        grad_row_stride, opt, flags, workspace, workspace_bytes, bounds_errors, feat_window, stream,
                         kPhasePrepare | kPhaseApply);
 }
 
 extern "C" int tbe_backward_prepare(const int64_t* feat_rows, const int64_t* feat_row_base, int32_t F, int32_t B,
                                     int32_t max_D, int32_t key_bits, const int64_t* indices, int64_t N,
                                     const int64_t* offsets, int32_t pooling_mode, int32_t flags, void* workspace,
-                                    size_t workspace_bytes, int32_t* bounds_errors, void* stream) {
+                                    size_t workspace_bytes, int32_t* bounds_errors, const int64_t* feat_window,
+                                    void* stream) {
   tbe_optimizer_args opt{};
   return backward_entry(nullptr, nullptr, nullptr, feat_rows, feat_row_base, nullptr, nullptr, F, B, max_D, key_bits,
                         indices, N, offsets, nullptr, pooling_mode, nullptr, 1, opt, flags & TBE_FLAG_WEIGHTED, workspace,
-                        workspace_bytes, bounds_errors, stream, kPhasePrepare);
+                        workspace_bytes, bounds_errors, feat_window, stream, kPhasePrepare);
 }
 
 extern "C" int tbe_backward_apply_f32(
@@ -919,7 +923,7 @@ extern "C" int tbe_backward_apply_f32(
     size_t workspace_bytes, void* stream) {
   return backward_entry(feat_weights, feat_D, feat_out_offset, feat_rows, feat_row_base, feat_state0, feat_state1, F,
                         B, max_D, key_bits, indices, N, offsets, per_sample_weights, pooling_mode, grad_out,
-                        grad_row_stride, opt, flags, workspace, workspace_bytes, nullptr, stream, kPhaseApply);
+                        grad_row_stride, opt, flags, workspace, workspace_bytes, nullptr, nullptr, stream, kPhaseApply);
 }
 
 // ---- the pair sort as a public entry (tests, micro-benchmarks) ---------------------------------------

@@ -58,7 +58,8 @@ __device__ __forceinline__ int64_t set_base(uint64_t key, int num_sets) {
 // position p -> feature (largest f with offsets[f*B] <= p), key of cached rows, pass-through of the rest
 __global__ __launch_bounds__(256) void cache_linearize_kernel(
     const int64_t* __restrict__ indices, const int64_t* __restrict__ offsets, const int32_t* __restrict__ feat_ctab,
-    const int64_t* __restrict__ feat_rows, const int64_t* __restrict__ tab_key_base, int F, int B, int64_t N,
+    const int64_t* __restrict__ feat_rows, const int64_t* __restrict__ feat_window,
+    const int64_t* __restrict__ tab_key_base, int F, int B, int64_t N,
     uint64_t sentinel, uint64_t* __restrict__ keys, uint64_t* __restrict__ payload, int64_t* __restrict__ remapped) {
   extern __shared__ int64_t fb[];
   for (int i = threadIdx.x; i <= F; i += blockDim.x) fb[i] = offsets[static_cast<int64_t>(i) * B];
@@ -75,11 +76,16 @@ __global__ __launch_bounds__(256) void cache_linearize_kernel(
     const int tc = feat_ctab[f];
     uint64_t key = sentinel;
     if (tc < 0) {
-      remapped[p] = idx;
-    } else if (static_cast<uint64_t>(idx) < static_cast<uint64_t>(feat_rows[f])) {
-      key = static_cast<uint64_t>(tab_key_base[tc] + idx);
+      remapped[p] = idx;  // not cached: the lookup kernels apply the feature's window themselves
     } else {
-      remapped[p] = -1;  // out of range: the lookup kernels count it and contribute a zero row
+      int64_t lidx;
+      const int cls = classify_id(load_window(feat_rows, feat_window, f), idx, lidx);
+      if (cls == kIdLocal) {
+        key = static_cast<uint64_t>(tab_key_base[tc] + lidx);
+      } else {
+        // another shard's row: skipped silently; out of range: the lookup kernels count it (zero row either way)
+        remapped[p] = cls == kIdForeign ? TBE_ID_SKIP : -1;
+      }
     }
     keys[p] = key;
     payload[p] = static_cast<uint64_t>(p);
@@ -342,7 +348,7 @@ extern "C" size_t tbe_cache_prefetch_workspace_bytes(int64_t N, int32_t key_bits
 extern "C" int tbe_cache_prefetch(const tbe_cache_desc* desc, const int32_t* feat_cached_table, const int64_t* feat_rows,
                                   int32_t F, int32_t B, const int64_t* indices, int64_t N, const int64_t* offsets,
                                   int32_t key_bits, int32_t iteration, int64_t* remapped_indices, void* workspace,
-                                  size_t workspace_bytes, void* stream) {
+                                  size_t workspace_bytes, const int64_t* feat_window, void* stream) {
   CacheDev c;
   int rc = to_dev(desc, &c);
   if (rc != TBE_OK) return rc;
@@ -372,7 +378,7 @@ extern "C" int tbe_cache_prefetch(const tbe_cache_desc* desc, const int32_t* fea
   TBE_REQUIRE(lds <= 60000, "tbe_cache_prefetch: too many features (%d)", F);
   const unsigned gridN = static_cast<unsigned>((N + 255) / 256);
   hipLaunchKernelGGL(cache_linearize_kernel, dim3(std::min<unsigned>(gridN, 256 * 16)), dim3(256), lds, st, indices, offsets,
-                     feat_cached_table, feat_rows, c.tab_key_base, F, B, N, sentinel, w.k0, w.p0, remapped_indices);
+                     feat_cached_table, feat_rows, feat_window, c.tab_key_base, F, B, N, sentinel, w.k0, w.p0, remapped_indices);
   TBE_CHECK_LAUNCH("tbe_cache_prefetch linearize");
   const int where = radix_sort_pairs<uint64_t, uint64_t>(w.k0, w.k1, w.p0, w.p1, N, key_bits, w.sort, st);
   if (where < 0) return where;

@@ -28,6 +28,7 @@ struct FwdArgs {
   const int32_t* feat_D;
   const int64_t* feat_out_offset;
   const int64_t* feat_rows;
+  const int64_t* feat_window;  // [2F] (first global row, global rows) per feature, or nullptr
   const int64_t* indices;
   const int64_t* offsets;
   const float* psw;
@@ -71,7 +72,6 @@ __device__ __forceinline__ void store_cols(float* row, int d, int D, bool vec, f
   }
 }
 
-constexpr int kFwdBagsPerBlock = 256;
 
 template <int G, int NV, bool WEIGHTED, bool MEAN>
 __global__ __launch_bounds__(256) void tbe_fwd_short_kernel(FwdArgs a) {
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void tbe_fwd_short_kernel(FwdArgs a) {
   const float* __restrict__ W = reinterpret_cast<const float*>(a.feat_weights[f]);
   const int D = a.feat_D[f];
   const int64_t Doff = a.feat_out_offset[f];
-  const int64_t rows = a.feat_rows[f];
+  const RowWindow win = load_window(a.feat_rows, a.feat_window, f);
   const bool vec = ((D & 3) == 0) && ((Doff & 3) == 0) && ((a.out_stride & 3) == 0) &&
                    ((reinterpret_cast<uintptr_t>(W) & 15) == 0) &&
                    ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0);
@@ -142,9 +142,11 @@ __global__ __launch_bounds__(256) void tbe_fwd_short_kernel(FwdArgs a) {
       float4 x[U][NV];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const bool ok = len[u] > 0 && static_cast<uint64_t>(idx[u]) < static_cast<uint64_t>(rows);
-        if (len[u] > 0 && !ok) ++nbad;
-        const float* row = W + idx[u] * D;
+        int64_t lix;
+        const int cls = classify_id(win, idx[u], lix);
+        const bool ok = len[u] > 0 && cls == kIdLocal;
+        if (len[u] > 0 && cls == kIdBad) ++nbad;
+        const float* row = W + lix * D;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
           const int d = (v * G + gl) * 4;
@@ -167,9 +169,11 @@ __global__ __launch_bounds__(256) void tbe_fwd_short_kernel(FwdArgs a) {
           ix = a.indices[s[u] + i];
           if (WEIGHTED) w[u] = a.psw[s[u] + i];
         }
-        const bool ok = in && static_cast<uint64_t>(ix) < static_cast<uint64_t>(rows);
-        if (in && !ok) ++nbad;
-        const float* row = W + ix * D;
+        int64_t lix;
+        const int cls = classify_id(win, ix, lix);
+        const bool ok = in && cls == kIdLocal;
+        if (in && cls == kIdBad) ++nbad;
+        const float* row = W + lix * D;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
           const int d = (v * G + gl) * 4;
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(256) void tbe_fwd_long_kernel(FwdArgs a) {
   const float* __restrict__ W = reinterpret_cast<const float*>(a.feat_weights[f]);
   const int D = a.feat_D[f];
   const int64_t Doff = a.feat_out_offset[f];
-  const int64_t rows = a.feat_rows[f];
+  const RowWindow win = load_window(a.feat_rows, a.feat_window, f);
   const bool vec = ((D & 3) == 0) && ((Doff & 3) == 0) && ((a.out_stride & 3) == 0) &&
                    ((reinterpret_cast<uintptr_t>(W) & 15) == 0) &&
                    ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0);
@@ -264,9 +268,11 @@ __global__ __launch_bounds__(256) void tbe_fwd_long_kernel(FwdArgs a) {
         const int64_t ix = shfl64(ix_l, j & 63);
         w[u] = WEIGHTED ? __shfl(w_l, j & 63, kWave) : 1.f;
         const bool in = j < n;
-        const bool ok = in && static_cast<uint64_t>(ix) < static_cast<uint64_t>(rows);
-        if (in && !ok) ++nbad;
-        const float* row = W + ix * D;
+        int64_t lix;
+        const int cls = classify_id(win, ix, lix);
+        const bool ok = in && cls == kIdLocal;
+        if (in && cls == kIdBad) ++nbad;
+        const float* row = W + lix * D;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
           const int d = (v * G + gl) * 4;
@@ -423,7 +429,7 @@ extern "C" int tbe_forward_pooled_f32(const uint64_t* feat_weights, const int32_
                                       const int64_t* indices, int64_t N, const int64_t* offsets,
                                       const float* per_sample_weights, int32_t pooling_mode,
                                       float* out, int64_t out_row_stride, int32_t* bounds_errors,
-                                      void* stream) {
+                                      const int64_t* feat_window, void* stream) {
   TBE_REQUIRE(F > 0 && B >= 0 && N >= 0, "tbe_forward_pooled_f32: bad sizes F=%d B=%d N=%lld", F, B,
               (long long)N);
   TBE_REQUIRE(pooling_mode == TBE_POOL_SUM || pooling_mode == TBE_POOL_MEAN,
@@ -435,7 +441,7 @@ extern "C" int tbe_forward_pooled_f32(const uint64_t* feat_weights, const int32_
               "tbe_forward_pooled_f32: null pointer");
   TBE_REQUIRE(N == 0 || indices != nullptr, "tbe_forward_pooled_f32: null indices");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  FwdArgs a{feat_weights, feat_D, feat_out_offset, feat_rows, indices, offsets, per_sample_weights,
+  FwdArgs a{feat_weights, feat_D, feat_out_offset, feat_rows, feat_window, indices, offsets, per_sample_weights,
             out, bounds_errors, out_row_stride, N, F, B, 64};
   // small launches: 4x more waves (16 bags each) keep more row reads in flight per CU
   if (static_cast<int64_t>(F) * B < (static_cast<int64_t>(1) << 19)) a.bags_per_wave = 16;

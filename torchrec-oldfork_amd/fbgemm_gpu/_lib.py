@@ -56,7 +56,7 @@ SIGNATURES = {
     "tbe_forward_pooled_f32": (
         ctypes.c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p, c_i64,
-         c_void_p, c_void_p, c_i32, c_void_p, c_i64, c_void_p, c_void_p],
+         c_void_p, c_void_p, c_i32, c_void_p, c_i64, c_void_p, c_void_p, c_void_p],
     ),
     "tbe_forward_nobag_f32": (
         ctypes.c_int,
@@ -68,12 +68,12 @@ SIGNATURES = {
         ctypes.c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32,
          c_i32, c_i32, c_void_p, c_i64, c_void_p, c_void_p, c_i32, c_void_p, c_i64, OptimizerArgs,
-         c_i32, c_void_p, c_size, c_void_p, c_void_p],
+         c_i32, c_void_p, c_size, c_void_p, c_void_p, c_void_p],
     ),
     "tbe_backward_prepare": (
         ctypes.c_int,
         [c_void_p, c_void_p, c_i32, c_i32, c_i32, c_i32, c_void_p, c_i64, c_void_p, c_i32, c_i32, c_void_p,
-         c_size, c_void_p, c_void_p],
+         c_size, c_void_p, c_void_p, c_void_p],
     ),
     "tbe_sort_pairs_workspace_bytes": (c_size, [c_i64, c_i32]),
     "tbe_sort_pairs": (
@@ -92,7 +92,7 @@ SIGNATURES = {
     "tbe_cache_prefetch": (
         ctypes.c_int,
         [ctypes.POINTER(CacheDesc), c_void_p, c_void_p, c_i32, c_i32, c_void_p, c_i64, c_void_p, c_i32, c_i32,
-         c_void_p, c_void_p, c_size, c_void_p],
+         c_void_p, c_void_p, c_size, c_void_p, c_void_p],
     ),
     "tbe_cache_writeback_staging": (ctypes.c_int, [ctypes.POINTER(CacheDesc), c_void_p]),
     "tbe_cache_flush": (ctypes.c_int, [ctypes.POINTER(CacheDesc), c_i32, c_void_p]),

@@ -115,6 +115,7 @@ class _Layout:
         self.feat_D = None
         self.feat_out_offset = None
         self.feat_rows = None
+        self.feat_window = None  # [2F] (first global row, global rows) of row-wise shards, or None
         self.feat_row_base = None
         self.feat_state0 = None
         self.feat_state1 = None
@@ -225,6 +226,13 @@ class _RowCache:
             r.feat_weights[cf] = self.rows.data_ptr()
             r.feat_rows = lay.feat_rows.clone()
             r.feat_rows[cf] = self.slots + self.staging_cap
+            r.feat_window = None
+            if lay.feat_window is not None:
+                # cached features arrive as slot numbers (or TBE_ID_SKIP / -1): their window is the pseudo-table's
+                r.feat_window = lay.feat_window.clone().view(-1, 2)
+                r.feat_window[cf, 0] = 0
+                r.feat_window[cf, 1] = self.slots + self.staging_cap
+                r.feat_window = r.feat_window.view(-1)
             r.feat_row_base = lay.feat_row_base.clone()
             r.feat_row_base[cf] = self.m.total_rows
             r.feat_D, r.feat_out_offset = lay.feat_D, lay.feat_out_offset
@@ -252,7 +260,7 @@ class _RowCache:
             ws = workspace(lib.tbe_cache_prefetch_workspace_bytes(N, self.key_bits), dev)
             check(lib.tbe_cache_prefetch(ctypes_byref(self.desc()), ptr(self.feat_ctab), ptr(real.feat_rows), self.m.F, B,
                                          ptr(indices), N, ptr(offsets), self.key_bits, self.iteration, ptr(out), ptr(ws),
-                                         ws.numel(), stream_ptr(dev)),
+                                         ws.numel(), ptr(real.feat_window), stream_ptr(dev)),
                   "tbe_cache_prefetch")
         self.pending = training
         self.dirty = self.dirty or training
@@ -354,6 +362,7 @@ class _TBEBase(nn.Module):
         self._layout = _Layout()
         self._cache: Optional[_RowCache] = None
         self._bounds_errors: Optional[torch.Tensor] = None
+        self._row_windows = None  # see set_row_windows
         self._side_stream = None
         # sort the batch's row keys on a side stream during forward (see _prepare_backward)
         # "auto": only for lookups small enough to leave CUs idle (measured on MI355X: at 1.7 M ids the
@@ -426,7 +435,7 @@ class _TBEBase(nn.Module):
     def _real_layout(self) -> _Layout:
         self._ensure_pinned()
         s0, s1 = self._state_ptrs()
-        key = (self._storage_key(), tuple(s0 or ()), tuple(s1 or ()))
+        key = (self._storage_key(), tuple(s0 or ()), tuple(s1 or ()), self._row_windows)
         lay = self._layout
         if lay.key == key:
             return lay
@@ -445,20 +454,54 @@ class _TBEBase(nn.Module):
         lay.feat_D = i32(self.feat_D)
         lay.feat_out_offset = i64(self.D_offsets[:-1])
         lay.feat_rows = i64([self.rows_per_table[t] for t in ftm])
+        lay.feat_window = None
+        if self._row_windows is not None:
+            lay.feat_window = i64([x for pair in zip(*self._row_windows) for x in pair])
         lay.feat_row_base = i64([self.row_base[t] for t in ftm])
         lay.feat_state0 = i64([s0[t] for t in ftm]) if s0 is not None else None
         lay.feat_state1 = i64([s1[t] for t in ftm]) if s1 is not None else None
         lay.key = key
         return lay
 
+    def set_row_windows(self, first_rows: Optional[List[int]], global_rows: Optional[List[int]] = None) -> None:
+        """Row-wise shards fed with un-bucketized GLOBAL ids: feature f's table holds global rows
+        [first_rows[f], first_rows[f] + rows); ids of other shards (inside [0, global_rows[f])) are skipped
+        silently, ids outside [0, global_rows[f]) count as bounds errors (include/tbe_hip.h `feat_window`).
+        The reference bucketizes instead (embedding_sharding.py:121-184).  None switches windows off."""
+        if first_rows is None:
+            self._row_windows = None
+            return
+        if len(first_rows) != self.F or len(global_rows) != self.F:
+            raise ValueError("set_row_windows: one (first row, global rows) pair per feature")
+        self._row_windows = (tuple(int(x) for x in first_rows), tuple(int(x) for x in global_rows))
+
     def _errors(self) -> torch.Tensor:
         if self._bounds_errors is None or self._bounds_errors.device != self.current_device:
             self._bounds_errors = torch.zeros(1, dtype=torch.int32, device=self.current_device)
         return self._bounds_errors
 
+    def _errors_ptr(self) -> Optional[int]:
+        """The counter the kernels increment, or NULL for BoundsCheckMode.IGNORE / NONE (an out-of-range id still
+        contributes a zero row and is never dereferenced: this build has no unchecked mode)."""
+        if getattr(self, "bounds_check_mode", BoundsCheckMode.WARNING) in (BoundsCheckMode.IGNORE, BoundsCheckMode.NONE):
+            return None
+        return ptr(self._errors())
+
     def bounds_check_errors(self) -> int:
-        """Number of out-of-range indices seen so far (they contribute zero rows). Syncs."""
+        """Number of out-of-range indices (and malformed bags) seen so far; they contribute zero rows.  Rows
+        that belong to another rank's shard (`set_row_windows`) are NOT errors.  Syncs."""
         return int(self._errors().item())
+
+    def _enforce_bounds_check_mode(self) -> None:
+        """BoundsCheckMode.FATAL: raise as soon as a lookup has seen a bad id (costs a host sync per call);
+        WARNING: warn once per new batch of errors is left to the caller reading bounds_check_errors()."""
+        if getattr(self, "bounds_check_mode", BoundsCheckMode.WARNING) != BoundsCheckMode.FATAL:
+            return
+        n = self.bounds_check_errors()
+        seen = getattr(self, "_fatal_seen", 0)
+        if n > seen:
+            self._fatal_seen = n
+            raise RuntimeError(f"BoundsCheckMode.FATAL: {n - seen} out-of-range indices or malformed bags in this lookup")
 
     # -- launches ---------------------------------------------------------------------------
     def _check_inputs(self, indices, offsets, per_sample_weights) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor], int]:
@@ -522,7 +565,7 @@ class _TBEBase(nn.Module):
                 check(
                     lib.tbe_forward_nobag_f32(ptr(lay.feat_weights), ptr(lay.feat_rows), self.F, B,
                                               D, ptr(indices), N, ptr(offsets), ptr(out),
-                                              ptr(self._errors()), stream_ptr(dev)),
+                                              self._errors_ptr(), stream_ptr(dev)),
                     "tbe_forward_nobag_f32",
                 )
                 return out
@@ -542,7 +585,7 @@ class _TBEBase(nn.Module):
                                            ptr(out_off), ptr(lay.feat_rows), self.F, B,
                                            self.max_D, ptr(indices), N, ptr(offsets),
                                            ptr(per_sample_weights), int(self.pooling_mode), ptr(out),
-                                           stride, ptr(self._errors()), stream_ptr(dev)),
+                                           stride, self._errors_ptr(), ptr(lay.feat_window), stream_ptr(dev)),
                 "tbe_forward_pooled_f32",
             )
         return out
@@ -573,7 +616,7 @@ class _TBEBase(nn.Module):
                 lib.tbe_backward_prepare(ptr(lay.feat_rows), ptr(lay.feat_row_base), self.F, B, self.max_D,
                                          self.key_bits, ptr(indices), N, ptr(offsets), int(self.pooling_mode),
                                          _FLAG_WEIGHTED if weighted else 0, ptr(ws), ws.numel(),
-                                         ptr(self._errors()), side.cuda_stream),
+                                         self._errors_ptr(), ptr(lay.feat_window), side.cuda_stream),
                 "tbe_backward_prepare",
             )
             ev = torch.cuda.Event()
@@ -631,7 +674,7 @@ class _TBEBase(nn.Module):
                                            self.max_D, self.key_bits, ptr(indices), N, ptr(offsets),
                                            ptr(per_sample_weights), int(self.pooling_mode),
                                            ptr(grad_out), stride, opt, flags, ptr(ws), ws.numel(),
-                                           ptr(self._errors()), stream_ptr(dev)),
+                                           self._errors_ptr(), ptr(lay.feat_window), stream_ptr(dev)),
                 "tbe_backward_fused_f32",
             )
 
@@ -877,8 +920,10 @@ class SplitTableBatchedEmbeddingBagsCodegen(_TBEBase):
         mode = self.overlap_backward_sort
         prepare = torch.is_grad_enabled() and (
             mode in (True, "1") or (mode == "auto" and indices.numel() <= self.overlap_backward_sort_max_ids))
-        return _FusedLookup.apply(self.placeholder_autograd_tensor, self, indices, offsets,
-                                  per_sample_weights, B, prepare)
+        out = _FusedLookup.apply(self.placeholder_autograd_tensor, self, indices, offsets,
+                                 per_sample_weights, B, prepare)
+        self._enforce_bounds_check_mode()
+        return out
 
     def forward_into(self, out: torch.Tensor, out_offsets: torch.Tensor, row_stride: int, indices: torch.Tensor,
                      offsets: torch.Tensor, per_sample_weights: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -890,8 +935,10 @@ class SplitTableBatchedEmbeddingBagsCodegen(_TBEBase):
         mode = self.overlap_backward_sort
         prepare = torch.is_grad_enabled() and (
             mode in (True, "1") or (mode == "auto" and indices.numel() <= self.overlap_backward_sort_max_ids))
-        return _FusedLookupInto.apply(out, self.placeholder_autograd_tensor, self, indices, offsets,
-                                      per_sample_weights, B, out_offsets, int(row_stride), prepare)
+        out = _FusedLookupInto.apply(out, self.placeholder_autograd_tensor, self, indices, offsets,
+                                     per_sample_weights, B, out_offsets, int(row_stride), prepare)
+        self._enforce_bounds_check_mode()
+        return out
 
 
 class _DenseLookup(torch.autograd.Function):

@@ -8,11 +8,13 @@ EmbeddingBagCollectionSharder (:489-515).  The data path is re-designed for xGMI
   reference (per sharding TYPE, embeddingbag.py:331-402)      this build (once, for all types)
   --------------------------------------------------------    ------------------------------------------
   kjt.permute + split                                          one gather of ids into send order
-  RW: block_bucketize + 2-phase lengths/values a2a + D2H sync  ids of row-wise features go to every rank,
-  TW: 2-phase lengths/values a2a + D2H sync                    rows outside a rank's block are masked by the
-  recat permute_2D on the receiver                             kernel's bounds check; with host-known pooling
-                                                               factors every size is static: ONE a2a, no sync,
-                                                               no recat (TBE consumes [src][feature][sample])
+  RW: block_bucketize + 2-phase lengths/values a2a + D2H sync  ids of row-wise features go to every rank as
+  TW: 2-phase lengths/values a2a + D2H sync                    GLOBAL rows; the kernels get each shard's row
+  recat permute_2D on the receiver                             window and skip other shards' rows silently
+                                                               (ids outside the TABLE still count as bounds
+                                                               errors); with host-known pooling factors every
+                                                               size is static: ONE a2a, no sync, no recat
+                                                               (TBE consumes [src][feature][sample])
   one TBE per (type, group) + cat                              ONE TBE per rank (row-wise shards + table-wise
                                                                tables), output written a2a-ready
   TW: a2a + split/cat; RW: ring reduce-scatter; cat            ONE a2a, then tbe_pooled_exchange_unpack (copy
@@ -318,9 +320,10 @@ class ShardedEmbeddingBagCollection(nn.Module):
                                                       table_name_to_parameter_sharding[c.name].compute_kernel))
             local_table_index[t] = len(self._local_tables) - 1
         ftm_local = [local_table_index[g_table[g]] for g in local_feats[me]]
-        row_base = [self._local_tables[i].row_offset for i in ftm_local]
-        self._has_rw = any(b != 0 for b in row_base) or any(lt.row_wise for lt in self._local_tables)
-        self._row_base = torch.tensor(row_base, dtype=torch.int64, device=dev).view(1, -1, 1)
+        # row-wise shards see un-bucketized GLOBAL ids: (first global row, global rows) per local feature
+        win_first = [self._local_tables[i].row_offset for i in ftm_local]
+        win_global = [self._local_tables[i].cfg.num_embeddings for i in ftm_local]
+        self._has_rw = any(lt.row_wise for lt in self._local_tables)
         fused_params = dict(fused_params or {})
         factory = tbe_factory or _default_tbe_factory
         self._emb_module = None
@@ -330,6 +333,8 @@ class ShardedEmbeddingBagCollection(nn.Module):
                 ftm_local * W, pooling_type_to_pooling_mode(cfgs[0].pooling), dev, fused_params)
             if self._exchange:
                 self._emb_module.set_a2a_output_layout(W)
+            if self._has_rw:
+                self._emb_module.set_row_windows(win_first * W, win_global * W)
             self._init_parameters()
             self._optim = EmbeddingFusedOptimizer(self._emb_module, [lt.cfg.name for lt in self._local_tables])
         else:
@@ -502,15 +507,12 @@ class ShardedEmbeddingBagCollection(nn.Module):
                     wk.wait()
                 if wk2 is not None:
                     wk2.wait()
-                vals = recv_v
-                if self._has_rw:
-                    vals = (recv_v.view(W, self._F_local, B * L) - self._row_base).view(-1)
                 ck = ("off", B, L)
                 offsets = self._kjt_cache.get(ck)
                 if offsets is None:
                     offsets = torch.arange(W * self._F_local * B + 1, dtype=torch.int64, device=self._device) * L
                     self._kjt_cache[ck] = offsets
-                return SparseFeaturesDist(vals, offsets, recv_w, B, dp_in)
+                return SparseFeaturesDist(recv_v, offsets, recv_w, B, dp_in)
 
             return _InputDistAwaitable(finish)
         # ---- data-dependent pooling factors: lengths a2a, D2H of the value counts, values a2a
@@ -544,14 +546,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
             if wk2 is not None:
                 wk2.wait()
             offsets = torch.ops.fbgemm.asynchronous_complete_cumsum(recv_l).long()
-            vals = recv_v
-            if self._has_rw:
-                # subtract the row-wise block start per (src, local feature) segment
-                seg = torch.repeat_interleave(
-                    self._row_base.view(1, -1).expand(W, -1).reshape(-1),
-                    recv_l.view(W * self._F_local, B).sum(dim=1).long())
-                vals = recv_v - seg
-            return SparseFeaturesDist(vals, offsets, recv_w, B, dp_in)
+            return SparseFeaturesDist(recv_v, offsets, recv_w, B, dp_in)
 
         return _InputDistAwaitable(finish_var)
 
