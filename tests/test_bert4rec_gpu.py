@@ -22,6 +22,30 @@ import _paths  # noqa: F401
 pytestmark = pytest.mark.gpu
 
 
+class _ItemHistoryEncoder(nn.Module):
+    """Test-local model of BERT4Rec's embedding side (what examples/bert4rec/models/bert4rec.py:323-408 computes for
+    its single "item" feature): unpooled lookup of the item ids through this package's EmbeddingCollection (fused
+    optimizer inside), left-aligned zero padding / truncation of every history to `length` rows with the
+    jagged_2d_to_dense kernel, a learned position term and a LayerNorm over (length, dim)."""
+
+    def __init__(self, num_items, length, dim, dev, fused_params):
+        super().__init__()
+        from torchrec_amd.modules.embedding_configs import EmbeddingConfig
+        from torchrec_amd.modules.embedding_modules import EmbeddingCollection
+
+        self.length, self.dim = length, dim
+        self.items = EmbeddingCollection(
+            tables=[EmbeddingConfig(name="item_embedding", embedding_dim=dim, num_embeddings=num_items, feature_names=["item"],
+                                    weight_init_min=-1.0, weight_init_max=1.0)], device=dev, fused_params=fused_params)
+        self.position = nn.Parameter(torch.randn(length, dim, device=dev))
+        self.norm = nn.LayerNorm([length, dim], device=dev)
+
+    def forward(self, histories):
+        rows = self.items(histories)["item"]  # JaggedTensor: one row per id
+        dense = torch.ops.fbgemm.jagged_2d_to_dense(rows.values(), rows.offsets(), self.length)
+        return self.norm(dense.view(-1, self.length, self.dim) + self.position)
+
+
 class _Top(nn.Module):
     def __init__(self, D, L, vocab, dev):
         super().__init__()
@@ -33,25 +57,23 @@ class _Top(nn.Module):
         return self.out(self.block(x))
 
 
-def test_history_arch_with_fused_adam_matches_sparse_adam_twin():
+def test_item_history_encoder_with_fused_adam_matches_sparse_adam_twin():
     from fbgemm_gpu.split_embedding_configs import EmbOptimType
-    from torchrec_amd.models.bert4rec import HistoryArch
     from torchrec_amd.sparse.jagged_tensor import KeyedJaggedTensor
 
     torch.manual_seed(0)
     dev = torch.device("cuda", 0)
     vocab, L, D, B, lr = 400, 8, 64, 24, 1e-2
-    hist = HistoryArch(vocab, L, D, dropout=0.0, device=dev,
-                       fused_params={"optimizer": EmbOptimType.ADAM, "learning_rate": lr, "eps": 1e-30, "beta1": 0.9,
-                                     "beta2": 0.999, "weight_decay": 0.0})
+    hist = _ItemHistoryEncoder(vocab, L, D, dev, {"optimizer": EmbOptimType.ADAM, "learning_rate": lr, "eps": 1e-30,
+                                                  "beta1": 0.9, "beta2": 0.999, "weight_decay": 0.0})
     top = _Top(D, L, vocab, dev)
     # twin
     emb2 = nn.Embedding(vocab, D, sparse=True, device=dev)
     with torch.no_grad():
-        emb2.weight.copy_(hist.ec.table_weights()["item_embedding"])
-    pos2 = nn.Parameter(hist.positional.detach().clone())
-    ln2, top2 = copy.deepcopy(hist.layernorm), copy.deepcopy(top)
-    opt_dense = torch.optim.Adam([hist.positional] + list(hist.layernorm.parameters()) + list(top.parameters()), lr=1e-3)
+        emb2.weight.copy_(hist.items.table_weights()["item_embedding"])
+    pos2 = nn.Parameter(hist.position.detach().clone())
+    ln2, top2 = copy.deepcopy(hist.norm), copy.deepcopy(top)
+    opt_dense = torch.optim.Adam([hist.position] + list(hist.norm.parameters()) + list(top.parameters()), lr=1e-3)
     opt_dense2 = torch.optim.Adam([pos2] + list(ln2.parameters()) + list(top2.parameters()), lr=1e-3)
     opt_emb2 = torch.optim.SparseAdam(list(emb2.parameters()), lr=lr, betas=(0.9, 0.999), eps=1e-30)
     rng = np.random.default_rng(1)
@@ -84,8 +106,8 @@ def test_history_arch_with_fused_adam_matches_sparse_adam_twin():
         opt_emb2.step()
         torch.testing.assert_close(loss, loss2, rtol=1e-4, atol=1e-5)
     torch.cuda.synchronize()
-    torch.testing.assert_close(hist.ec.table_weights()["item_embedding"], emb2.weight.detach(), rtol=1e-3, atol=2e-5)
-    torch.testing.assert_close(hist.positional.detach(), pos2.detach(), rtol=1e-3, atol=2e-5)
+    torch.testing.assert_close(hist.items.table_weights()["item_embedding"], emb2.weight.detach(), rtol=1e-3, atol=2e-5)
+    torch.testing.assert_close(hist.position.detach(), pos2.detach(), rtol=1e-3, atol=2e-5)
 
 
 def test_fused_adagrad_matches_torch_sparse_adagrad():

@@ -24,7 +24,7 @@ to rank r, the looked-up rows come back in bucketized order and `unbucketize_per
 caller's order with one index_select (dist_data.py:820-827).  Table-wise and row-wise tables of one
 collection run as two independent paths over disjoint features.
 """
-from typing import Any, Callable, Dict, List, Optional
+from typing import Any, Callable, Dict, List, Optional, NamedTuple
 
 import torch
 import torch.distributed as dist
@@ -32,12 +32,34 @@ from torch import nn
 
 from ..modules.embedding_configs import EmbeddingConfig
 from ..sparse.jagged_tensor import JaggedTensor, KeyedJaggedTensor
-from .embedding_sharding import bucketize_kjt_before_all2all
 from .planner import rw_block_size, rw_shard_rows
 from .types import Awaitable, LazyAwaitable, NoWait, ParameterSharding, ShardingEnv, ShardingType
 
 
 SEQUENCE_GRADIENT_DIVISION = False  # reference behaviour (see the module docstring)
+
+
+class RowBlockSplit(NamedTuple):
+    """Ids regrouped by the rank that holds their row: segment (dest, feature, sample) order."""
+
+    lengths: torch.Tensor            # [num_dest * F * B] ids per (dest, feature, sample)
+    ids: torch.Tensor                # [N] row numbers INSIDE the destination's block, segment order
+    weights: Optional[torch.Tensor]  # [N] per-id weights in the same order, if given
+    restore: Optional[torch.Tensor]  # [N] restore[i] = position of the caller's i-th id in `ids`
+
+
+def split_ids_by_row_block(lengths: torch.Tensor, ids: torch.Tensor, rows_per_block: List[int], num_dest: int,
+                           weights: Optional[torch.Tensor] = None, want_restore: bool = True) -> RowBlockSplit:
+    """Row-wise input dist, step 1: feature f's id goes to rank id // rows_per_block[f] and becomes
+    id % rows_per_block[f] there (block size ceil(rows / W): sharding/rw_sharding.py:229-236).  One launch of the
+    bucketize kernel (csrc/sparse_ops.hip, through the `fbgemm::block_bucketize_sparse_features` op the
+    reference's KJT-level wrapper calls at embedding_sharding.py:160-168); stable inside a bag."""
+    blocks = torch.as_tensor(rows_per_block, dtype=ids.dtype, device=ids.device)
+    if blocks.numel() * num_dest == 0 or lengths.numel() % blocks.numel():
+        raise ValueError(f"split_ids_by_row_block: {lengths.numel()} lengths do not divide into {blocks.numel()} features")
+    new_lengths, new_ids, new_weights, _pos, restore = torch.ops.fbgemm.block_bucketize_sparse_features(
+        lengths.reshape(-1), ids, False, want_restore, blocks, num_dest, weights)
+    return RowBlockSplit(new_lengths.reshape(-1), new_ids, new_weights, restore)
 
 
 def _default_seq_tbe_factory(specs, ftm, device, fused_params):
@@ -164,9 +186,8 @@ class ShardedEmbeddingCollection(nn.Module):
         sub = features if order == list(range(len(features.keys()))) else features.permute(order)
         lengths, values = sub.lengths(), sub.values()
         Frw = len(self._rw_feats)
-        blocks = torch.tensor(self._rw_blocks, dtype=values.dtype, device=values.device)
-        bucketized, unb = bucketize_kjt_before_all2all(sub, W, blocks, output_permute=True)
-        nl, ni = bucketized.lengths(), bucketized.values()
+        split = split_ids_by_row_block(lengths, values, self._rw_blocks, W)
+        nl, ni, unb = split.lengths, split.ids, split.restore
         if W > 1:
             val_in = nl.view(W, -1).sum(dim=1).cpu().tolist()  # host sync (dist_data.py:396-398)
             recv_l = torch.empty(W * Frw * B, dtype=nl.dtype, device=nl.device)
