@@ -984,6 +984,12 @@ class DenseTableBatchedEmbeddingBagsCodegen(_TBEBase):
     def _flat_weights(self, placement: str) -> torch.Tensor:
         return self.weights if placement == "dev" else self._empty
 
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        # inside a sharded collection the tables travel as `embedding_bags.<table>.weight` (loaded by the owner)
+        if getattr(self, "_owned_by_sharded_module", False):
+            return
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
     def _dense_grad_ptrs(self, grad_w: torch.Tensor) -> torch.Tensor:
         """Per-feature base addresses inside a dense gradient buffer, computed on the device (a
         host-built table would cost a blocking H2D copy in every backward)."""

@@ -173,6 +173,47 @@ class ShardedEmbeddingCollection(nn.Module):
                         for t, w in zip(self._rw_table_ids, self._rw_module.split_embedding_weights())})
         return out
 
+    # ---- checkpoint surface (keys as torchrec/distributed/embedding.py: `embeddings.<table>.weight`) ----------
+    def state_dict(self, destination=None, prefix: str = "", keep_vars: bool = False):
+        destination = {} if destination is None else destination
+        for name, w in self.local_shards().items():
+            destination[f"{prefix}embeddings.{name}.weight"] = w if keep_vars else w.detach()
+        return destination
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        """Per table either the local shard or the whole table (cut at this rank's row offset)."""
+        row0 = self.local_shard_row_offsets()
+        rows = {c.name: c.num_embeddings for c in self._configs}
+        for name, w in self.local_shards().items():
+            key = f"{prefix}embeddings.{name}.weight"
+            if key not in state_dict:
+                if strict:
+                    missing_keys.append(key)
+                continue
+            src = state_dict[key]
+            if tuple(src.shape) != tuple(w.shape):
+                if src.dim() == 2 and src.shape[0] == rows[name] and src.shape[1] == w.shape[1]:
+                    src = src[row0[name]:row0[name] + w.shape[0]]
+                else:
+                    error_msgs.append(f"size mismatch for {key}: {tuple(src.shape)} vs local {tuple(w.shape)}")
+                    continue
+            with torch.no_grad():
+                w.copy_(src)
+
+    @property
+    def fused_optimizer(self):
+        from ..optim.keyed import CombinedOptimizer
+        from .embeddingbag import EmbeddingFusedOptimizer
+
+        opts = []
+        if self._emb_module is not None:
+            opts.append(EmbeddingFusedOptimizer(self._emb_module, [self._configs[t].name for t in self._local_table_ids],
+                                                key_prefix="embeddings."))
+        if self._rw_module is not None:
+            opts.append(EmbeddingFusedOptimizer(self._rw_module, [self._configs[t].name for t in self._rw_table_ids],
+                                                key_prefix="embeddings."))
+        return CombinedOptimizer(opts)
+
     def local_shard_row_offsets(self) -> Dict[str, int]:
         out = {self._configs[t].name: 0 for t in self._local_table_ids}
         if self._rw_module is not None:

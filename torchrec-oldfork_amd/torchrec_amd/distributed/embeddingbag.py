@@ -193,20 +193,42 @@ class _OutputAwaitable(LazyAwaitable):
 
 
 class EmbeddingFusedOptimizer:
-    """Optimizer facade over the TBE's in-backward optimizer
-    (torchrec/distributed/batched_embedding_kernel.py:53-257): `step()`/`zero_grad()` only push
-    the learning rate; parameters are the local table shards."""
+    """Optimizer facade over the TBE's in-backward optimizer (torchrec/distributed/batched_embedding_kernel.py:53-257):
+    `step()` / `zero_grad()` only push the learning rate; parameters are the local table shards.  Keys follow the
+    reference: parameter `<prefix><table>.weight`, its state `{"<table>.momentum1": ..., "<table>.momentum2": ...}`
+    nested under the parameter key (:241-249).  Tensors are views of the module's storage; for MANAGED_CACHING
+    tables the HBM row cache is written back before they are handed out."""
 
-    def __init__(self, emb_module, table_names: List[str]) -> None:
+    def __init__(self, emb_module, table_names: List[str], key_prefix: str = "") -> None:
         self._emb_module = emb_module
-        weights = emb_module.split_embedding_weights()
-        self.params: Dict[str, torch.Tensor] = {f"{n}.weight": w for n, w in zip(table_names, weights)}
-        self.param_groups = [{"params": list(self.params.values()),
-                              "lr": emb_module.optimizer_args.learning_rate}]
-        self.state: Dict[str, Any] = {}
-        for n, st in zip(table_names, emb_module.split_optimizer_states()):
-            for i, s in enumerate(st):
-                self.state[f"{n}.momentum{i + 1}"] = s
+        self._table_names = list(table_names)
+        self._key_prefix = key_prefix
+        self._save_param_groups = False
+        self.param_groups = [{"params": [], "lr": emb_module.optimizer_args.learning_rate}]
+        self._refresh()
+
+    def _refresh(self) -> None:
+        """(Re)reads the weight / state views: split_* write the row cache back and empty it first."""
+        m, pre = self._emb_module, self._key_prefix
+        self._params = {f"{pre}{n}.weight": w for n, w in zip(self._table_names, m.split_embedding_weights())}
+        self._state = {f"{pre}{n}.weight": {f"{n}.momentum{i + 1}": s for i, s in enumerate(st)}
+                       for n, st in zip(self._table_names, m.split_optimizer_states())}
+        self.param_groups[0]["params"] = list(self._params.values())
+
+    def _cached(self) -> bool:
+        return getattr(self._emb_module, "_cache", None) is not None
+
+    @property
+    def params(self) -> Dict[str, torch.Tensor]:
+        if self._cached():
+            self._refresh()
+        return self._params
+
+    @property
+    def state(self) -> Dict[str, Dict[str, torch.Tensor]]:
+        if self._cached():
+            self._refresh()
+        return self._state
 
     def zero_grad(self, set_to_none: bool = False) -> None:
         self._emb_module.set_learning_rate(self.param_groups[0]["lr"])
@@ -214,8 +236,29 @@ class EmbeddingFusedOptimizer:
     def step(self, closure: Any = None) -> None:
         self._emb_module.set_learning_rate(self.param_groups[0]["lr"])
 
+    def save_param_groups(self, save: bool) -> None:
+        self._save_param_groups = save
+
     def state_dict(self) -> Dict[str, Any]:
-        return {"state": dict(self.state), "param_groups": [{"lr": self.param_groups[0]["lr"]}]}
+        out: Dict[str, Any] = {"state": {k: dict(v) for k, v in self.state.items()}}
+        if self._save_param_groups:
+            out["param_groups"] = [{"params": sorted(self._params.keys()), "lr": self.param_groups[0]["lr"]}]
+        return out
+
+    def load_state_dict(self, state_dict: Dict[str, Any]) -> None:
+        mine = self.state
+        new = state_dict["state"]
+        if set(new.keys()) != set(mine.keys()):
+            raise ValueError(f"fused optimizer state keys differ: {sorted(mine.keys())} vs {sorted(new.keys())}")
+        with torch.no_grad():
+            for k, st in new.items():
+                if set(st.keys()) != set(mine[k].keys()):
+                    raise ValueError(f"fused optimizer state of {k}: {sorted(mine[k].keys())} vs {sorted(st.keys())}")
+                for name, t in st.items():
+                    mine[k][name].copy_(t)
+        if "param_groups" in state_dict and state_dict["param_groups"]:
+            self.param_groups[0]["lr"] = state_dict["param_groups"][0].get("lr", self.param_groups[0]["lr"])
+            self._emb_module.set_learning_rate(self.param_groups[0]["lr"])
 
 
 class ShardedEmbeddingBagCollection(nn.Module):
@@ -336,7 +379,8 @@ class ShardedEmbeddingBagCollection(nn.Module):
             if self._has_rw:
                 self._emb_module.set_row_windows(win_first * W, win_global * W)
             self._init_parameters()
-            self._optim = EmbeddingFusedOptimizer(self._emb_module, [lt.cfg.name for lt in self._local_tables])
+            self._optim = EmbeddingFusedOptimizer(self._emb_module, [lt.cfg.name for lt in self._local_tables],
+                                                  key_prefix="embedding_bags.")
         else:
             self._optim = None
         # global-column addressing of the sharded features for the world_size == 1 "write into one buffer" path
@@ -352,6 +396,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
             dpf = dp_tbe_factory or _default_dp_tbe_factory
             self._dp_module = dpf([(cfgs[t].num_embeddings, cfgs[t].embedding_dim) for t in self._dp_table_ids], dp_ftm,
                                   pooling_type_to_pooling_mode(cfgs[0].pooling), dev)
+            self._dp_module._owned_by_sharded_module = True  # its weights load / save as embedding_bags.<t>.weight
             for t, w in zip(self._dp_table_ids, self._dp_module.split_embedding_weights()):
                 w.uniform_(cfgs[t].get_weight_init_min(), cfgs[t].get_weight_init_max())
             self._dp_out_off = torch.tensor([out_col[g] for g in self._dp_feats], dtype=torch.int64, device=dev)
@@ -394,10 +439,44 @@ class ShardedEmbeddingBagCollection(nn.Module):
                 for lt, w in zip(self._local_tables, self._emb_module.split_embedding_weights())}
 
     def state_dict(self, destination=None, prefix: str = "", keep_vars: bool = False):
+        """`embedding_bags.<table>.weight` for EVERY table this rank holds (embeddingbag.py:405-416): the local
+        shard [rows_local, D] of a sharded table, the whole [rows, D] of a replicated one.  The tensors alias
+        the modules' storage (host views, cache written back, for MANAGED_CACHING tables)."""
         destination = {} if destination is None else destination
         for name, (w, _) in self.local_shards().items():
-            destination[f"{prefix}embedding_bags.{name}.weight"] = w  # key as embeddingbag.py:416
+            destination[f"{prefix}embedding_bags.{name}.weight"] = w if keep_vars else w.detach()
+        for name, w in self.dp_tables().items():
+            destination[f"{prefix}embedding_bags.{name}.weight"] = w if keep_vars else w.detach()
         return destination
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        """Accepts, per table, either the local shard or the WHOLE table (rows are then cut at this rank's row
+        offset, as the reference's tests load a global model into shards: test_model_parallel_base.py:92-122)."""
+        targets = {n: (w, r0, False) for n, (w, r0) in self.local_shards().items()}
+        targets.update({n: (w, 0, True) for n, w in self.dp_tables().items()})
+        cfg = {c.name: c for c in self._embedding_bag_configs}
+        for name, (w, row0, _) in targets.items():
+            key = f"{prefix}embedding_bags.{name}.weight"
+            if key not in state_dict:
+                if strict:
+                    missing_keys.append(key)
+                continue
+            src = state_dict[key]
+            if tuple(src.shape) == tuple(w.shape):
+                pass
+            elif src.dim() == 2 and src.shape[0] == cfg[name].num_embeddings and src.shape[1] == w.shape[1]:
+                src = src[row0:row0 + w.shape[0]]
+            else:
+                error_msgs.append(f"size mismatch for {key}: {tuple(src.shape)} vs local {tuple(w.shape)} / global "
+                                  f"({cfg[name].num_embeddings}, {w.shape[1]})")
+                continue
+            with torch.no_grad():
+                w.copy_(src)
+        if strict:
+            mine = {f"{prefix}embedding_bags.{n}.weight" for n in cfg}
+            for k in state_dict.keys():
+                if k.startswith(prefix + "embedding_bags.") and k not in mine:
+                    unexpected_keys.append(k)
 
     def dp_tables(self) -> Dict[str, torch.Tensor]:
         """table name -> replicated weight [rows, D] (a view of the dense TBE's parameter)."""

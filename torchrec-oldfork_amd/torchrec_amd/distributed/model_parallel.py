@@ -32,6 +32,7 @@ class DistributedModelParallel(nn.Module):
         planner = planner or EmbeddingShardingPlanner(Topology(env.world_size, self.device.type))
         self._plan = plan or ShardingPlan()
         self._sharded: List[ShardedEmbeddingBagCollection] = []
+        self._sharded_paths: List[str] = []
         self._shard_modules(module, "", sharder, planner)
         self._dmp_wrapped_module = module
         self._ddp_wrapped = False
@@ -49,6 +50,7 @@ class DistributedModelParallel(nn.Module):
                 sharded = sharder.shard(child, params, self._env, self.device)
                 setattr(module, name, sharded)
                 self._sharded.append(sharded)
+                self._sharded_paths.append(child_path)
             else:
                 self._shard_modules(child, child_path, sharder, planner)
 
@@ -114,7 +116,15 @@ class DistributedModelParallel(nn.Module):
 
     @property
     def fused_optimizer(self) -> CombinedOptimizer:
-        return CombinedOptimizer([s.fused_optimizer for s in self._sharded if s.fused_optimizer is not None])
+        """Keys as the reference's (model_parallel.py:455-470): `<module path>.embedding_bags.<table>.weight`."""
+        return CombinedOptimizer([(path, s.fused_optimizer) for path, s in zip(self._sharded_paths, self._sharded)
+                                  if s.fused_optimizer is not None])
+
+    def state_dict(self, destination=None, prefix: str = "", keep_vars: bool = False):
+        return self.module.state_dict(destination=destination, prefix=prefix, keep_vars=keep_vars)
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        return self.module.load_state_dict(state_dict, strict=strict)
 
     def forward(self, *args, **kwargs):
         return self._dmp_wrapped_module(*args, **kwargs)
