@@ -43,7 +43,11 @@ class TorchRefDLRM(nn.Module):
         return y.squeeze(-1)
 
 
-def test_dlrm_training_matches_plain_torch_reference():
+@pytest.mark.parametrize("host_batches", [False, True])
+def test_dlrm_training_matches_plain_torch_reference(host_batches):
+    """host_batches: the batches live in PINNED HOST memory, so the pipeline's memcpy stream really copies batch
+    i + 2 while batch i trains and batch i + 1's ids are in flight on the data_dist stream (device-resident
+    batches make `.to()` a no-op); a missing record_stream shows as corrupted inputs here."""
     from torchrec_amd.datasets.random import RandomRecDataset
     from torchrec_amd.distributed.embeddingbag import EmbeddingBagCollectionSharder
     from torchrec_amd.distributed.model_parallel import DistributedModelParallel
@@ -86,9 +90,11 @@ def test_dlrm_training_matches_plain_torch_reference():
     ref_opt = torch.optim.SGD(ref.parameters(), lr=lr)
     data = RandomRecDataset(keys, B, rows, manual_seed=5, num_generated_batches=6, num_batches=6, device=dev)
     batches = list(iter(data))
+    feed = [b.to(torch.device("cpu")).pin_memory() for b in batches] if host_batches else batches
+    torch.cuda.synchronize()
     pipe = TrainPipelineSparseDist(model, opt, dev)
     model.train()
-    it = iter(batches)
+    it = iter(feed)
     bce = nn.BCEWithLogitsLoss()
     for step in range(6):
         loss = pipe.progress(it)[0]  # DLRMTrain output = (loss.detach(), logits, labels)

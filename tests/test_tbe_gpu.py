@@ -92,7 +92,7 @@ def test_forward_vs_oracle(case):
 OPTS = [
     ("EXACT_SGD", {}),
     ("EXACT_ROWWISE_ADAGRAD", dict(eps=1e-3)),
-    ("EXACT_ROWWISE_ADAGRAD", dict(eps=1e-3, weight_decay=0.01)),
+    ("EXACT_ROWWISE_ADAGRAD", dict(eps=1e-3, weight_decay=0.01, weight_decay_mode=1)),  # WeightDecayMode.L2
     ("EXACT_ADAGRAD", dict(eps=1e-3)),
     ("ADAM", dict(eps=1e-3, weight_decay=0.02)),
 ]
@@ -520,3 +520,22 @@ def test_bounds_check_modes():
         with pytest.raises(RuntimeError, match="BoundsCheckMode.FATAL: 2 out-of-range"):
             m(idx, off)
         assert m(torch.tensor([1, 2, 3, 4], dtype=torch.int64, device=dev), off).sum().item() == 32.0  # valid lookups go on
+
+
+def test_unimplemented_weight_decay_forms_raise():
+    """A (weight_decay, mode) pair this build does not implement raises at construction instead of computing another
+    form silently (row-wise Adagrad: L2 only; ADAM: decoupled only; SGD / Adagrad: none)."""
+    from fbgemm_gpu.split_embedding_configs import EmbOptimType
+    from fbgemm_gpu.split_table_batched_embeddings_ops import (ComputeDevice, EmbeddingLocation,
+                                                                SplitTableBatchedEmbeddingBagsCodegen, WeightDecayMode)
+
+    spec = [(10, 8, EmbeddingLocation.DEVICE, ComputeDevice.CUDA)]
+    dev = torch.device("cuda", 0)
+    for opt, mode in ((EmbOptimType.EXACT_ROWWISE_ADAGRAD, WeightDecayMode.NONE), (EmbOptimType.EXACT_ROWWISE_ADAGRAD, WeightDecayMode.DECOUPLE),
+                      (EmbOptimType.ADAM, WeightDecayMode.L2), (EmbOptimType.EXACT_SGD, WeightDecayMode.L2)):
+        with pytest.raises(NotImplementedError, match="weight_decay"):
+            SplitTableBatchedEmbeddingBagsCodegen(spec, device=dev, optimizer=opt, weight_decay=1e-5, weight_decay_mode=mode)
+    SplitTableBatchedEmbeddingBagsCodegen(spec, device=dev, optimizer=EmbOptimType.EXACT_ROWWISE_ADAGRAD, weight_decay=1e-5,
+                                          weight_decay_mode=WeightDecayMode.L2)
+    SplitTableBatchedEmbeddingBagsCodegen(spec, device=dev, optimizer=EmbOptimType.ADAM, weight_decay=1e-5)  # bert4rec_main.py:488-491
+    SplitTableBatchedEmbeddingBagsCodegen(spec, device=dev, optimizer=EmbOptimType.EXACT_ROWWISE_ADAGRAD, weight_decay=0.0)

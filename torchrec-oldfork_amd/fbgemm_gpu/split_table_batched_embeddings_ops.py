@@ -800,6 +800,19 @@ class SplitTableBatchedEmbeddingBagsCodegen(_TBEBase):
             raise NotImplementedError(f"optimizer {optimizer} is not implemented")
         if gradient_clipping:
             raise NotImplementedError("gradient_clipping is not implemented")
+        # weight decay: one form per optimizer is implemented (parity unpinned: fbgemm's is absent);
+        # any other request raises instead of silently computing something else
+        wdm = WeightDecayMode(int(weight_decay_mode))
+        if weight_decay != 0.0:
+            if optimizer == OptimType.EXACT_ROWWISE_ADAGRAD and wdm != WeightDecayMode.L2:
+                raise NotImplementedError("EXACT_ROWWISE_ADAGRAD implements weight_decay as L2 (g += weight_decay * w before "
+                                          f"the row-wise moment): pass weight_decay_mode=WeightDecayMode.L2, not {wdm.name}")
+            if optimizer == OptimType.ADAM and wdm == WeightDecayMode.L2:
+                raise NotImplementedError("ADAM implements weight_decay in the decoupled form (w -= lr * weight_decay * w, as "
+                                          "examples/bert4rec/bert4rec_main.py:488-491 uses it with the default mode); "
+                                          "WeightDecayMode.L2 is not implemented")
+            if optimizer in (OptimType.EXACT_SGD, OptimType.EXACT_ADAGRAD):
+                raise NotImplementedError(f"weight_decay is not implemented for {optimizer}")
         self._init_tables(list(rows), list(dims), list(locations), feature_table_map,
                           pooling_mode, device)
         self.optimizer = optimizer

@@ -472,6 +472,12 @@ class ShardedEmbeddingBagCollection(nn.Module):
                 continue
             with torch.no_grad():
                 w.copy_(src)
+        # the replicated tables' dense module is a registered child: nn.Module.load_state_dict will visit it after this
+        # method; hand it its own (just restored) storage under the key it expects, so that strict loading of a
+        # reference-shaped checkpoint (embedding_bags.<table>.weight only) does not report it missing
+        if self._dp_module is not None:
+            for k, v in nn.Module.state_dict(self._dp_module).items():
+                state_dict.setdefault(f"{prefix}_dp_module.{k}", v)
         if strict:
             mine = {f"{prefix}embedding_bags.{n}.weight" for n in cfg}
             for k in state_dict.keys():

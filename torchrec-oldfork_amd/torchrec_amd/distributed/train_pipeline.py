@@ -77,6 +77,12 @@ class TrainPipelineSparseDist:
         return batch.to(self._device, non_blocking=non_blocking) if batch is not None else None
 
     def _start_data_dist(self, batch) -> None:
+        """Called with the data_dist stream current: the ids were copied on the memcpy stream, so the caching
+        allocator must learn that this stream reads them too (the reference's `_wait_for_batch`,
+        train_pipeline.py:58-71, 228) — otherwise dropping the batch lets the next host-to-device copy reuse the
+        blocks while the id exchange is still queued."""
+        if self._data_dist_stream is not None:
+            batch.sparse_features.record_stream(self._data_dist_stream)
         for s in self._sharded:
             self._requests[id(s)] = s.input_dist(batch.sparse_features)
 
@@ -111,6 +117,10 @@ class TrainPipelineSparseDist:
         else:
             self._batch_ip2 = self._to_device(next(dataloader_iter, None), False)
         batch = self._batch_i
+        if self._memcpy_stream is not None:
+            # dense features, labels (and ids, for un-pipelined modules) are read by forward AND backward on this
+            # stream long after `progress` has dropped its reference to the batch
+            batch.record_stream(torch.cuda.current_stream())
         if self._model.training:
             self._optimizer.zero_grad()
         fwd_event = torch.cuda.Event() if self._data_dist_stream is not None else None
