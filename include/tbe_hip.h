@@ -115,6 +115,10 @@ int tbe_profile_read_rows(int64_t* rows_updated);
  *                [0, rows); such an index contributes a zero row (never dereferenced).  Also incremented for
  *                every bag whose offsets are malformed (start < 0, end > N, start > end): such a bag is
  *                empty in forward and contributes nothing in backward — no memory is touched through it.
+ * feat_pooling   optional [F] int32 (TBE_POOL_SUM / TBE_POOL_MEAN per feature), honoured when pooling_mode is
+ *                TBE_POOL_MEAN: tables of both pooling types in ONE lookup (the reference builds one TBE per
+ *                pooling type and concatenates: embedding_sharding.py:393-490, embedding_lookup.py:219-253).
+ *                NULL = every feature pools as pooling_mode says.  Same parameter in tbe_backward_*.
  * feat_window    optional [2F] int64: (first global row held, global rows of the table) per feature, for
  *                row-wise shards whose ids arrive un-bucketized (the reference bucketizes instead:
  *                torchrec/distributed/embedding_sharding.py:121-184, sharding/rw_sharding.py:229-236).  Ids are
@@ -127,7 +131,7 @@ int tbe_forward_pooled_f32(const uint64_t* feat_weights, const int32_t* feat_D,
                            const int64_t* feat_out_offset, const int64_t* feat_rows, int32_t F,
                            int32_t B, int32_t max_D, const int64_t* indices,
                            int64_t N, const int64_t* offsets, const float* per_sample_weights,
-                           int32_t pooling_mode, float* out, int64_t out_row_stride,
+                           int32_t pooling_mode, const int32_t* feat_pooling, float* out, int64_t out_row_stride,
                            int32_t* bounds_errors, const int64_t* feat_window, void* stream);
 
 /* TBE forward, PoolingMode.NONE (sequence / unpooled): out[i, :] = W_f(i)[indices[i], :]
@@ -169,7 +173,7 @@ int tbe_backward_fused_f32(const uint64_t* feat_weights, const int32_t* feat_D,
                            const uint64_t* feat_state1, int32_t F, int32_t B,
                            int32_t max_D, int32_t key_bits, const int64_t* indices, int64_t N,
                            const int64_t* offsets, const float* per_sample_weights,
-                           int32_t pooling_mode, const float* grad_out,
+                           int32_t pooling_mode, const int32_t* feat_pooling, const float* grad_out,
                            int64_t grad_row_stride, tbe_optimizer_args opt, int32_t flags,
                            void* workspace, size_t workspace_bytes, int32_t* bounds_errors, const int64_t* feat_window,
                            void* stream);
@@ -208,7 +212,7 @@ int tbe_backward_apply_f32(const uint64_t* feat_weights, const int32_t* feat_D,
                            const uint64_t* feat_state1, int32_t F, int32_t B,
                            int32_t max_D, int32_t key_bits, const int64_t* indices, int64_t N,
                            const int64_t* offsets, const float* per_sample_weights,
-                           int32_t pooling_mode, const float* grad_out,
+                           int32_t pooling_mode, const int32_t* feat_pooling, const float* grad_out,
                            int64_t grad_row_stride, tbe_optimizer_args opt, int32_t flags,
                            void* workspace, size_t workspace_bytes, void* stream);
 

@@ -20,19 +20,46 @@ class _Fn(torch.autograd.Function):
                                     psw.numpy() if psw is not None else None, mod.pooling)
         if mod.pooling == oracle.POOL_NONE:
             return torch.from_numpy(out)
-        return mod._to_layout(torch.from_numpy(out))
+        return mod._to_layout(mod._scale_blocks(torch.from_numpy(out), offsets))
 
     @staticmethod
     def backward(ctx, grad):
         indices, offsets, psw = ctx.saved_tensors
         mod = ctx.mod
-        g = grad.contiguous() if mod.pooling == oracle.POOL_NONE else mod._from_layout(grad.contiguous())
+        g = grad.contiguous() if mod.pooling == oracle.POOL_NONE else mod._scale_blocks(mod._from_layout(grad.contiguous()), offsets)
+        g = g.contiguous()
         oracle.tbe_backward(mod.tables, indices.numpy(), offsets.numpy(), g.numpy(), oracle.OPT_EXACT_SGD,
                             mod.optimizer_args.learning_rate, psw.numpy() if psw is not None else None, mod.pooling)
         return None, None, None, None, None
 
 
-class OracleTBE(nn.Module):
+class _MixedPooling:
+    def set_feature_pooling(self, modes):
+        """Mixed SUM / MEAN features: computed as SUM, MEAN features' blocks scaled by 1 / bag length (forward) and
+        their gradient blocks scaled the same way (backward) — the same arithmetic the kernels do per feature."""
+        self._feat_mean = None if modes is None else [int(m) == oracle.POOL_MEAN for m in modes]
+        if modes is not None:
+            self.pooling = oracle.POOL_SUM
+
+    def _mean_scale(self, offsets):
+        """[B, F] factors (1 for SUM features, 1 / len for MEAN ones; 0 for empty bags), or None."""
+        fm = getattr(self, "_feat_mean", None)
+        if not fm:
+            return None
+        B = (offsets.numel() - 1) // self.F
+        lens = (offsets[1:] - offsets[:-1]).view(self.F, B).t().float()
+        inv = torch.where(lens > 0, 1.0 / lens.clamp(min=1), torch.zeros_like(lens))
+        return torch.where(torch.tensor(fm).view(1, -1), inv, torch.ones_like(inv))
+
+    def _scale_blocks(self, x, offsets):
+        sc = self._mean_scale(offsets)
+        if sc is None:
+            return x
+        cols = torch.repeat_interleave(sc, torch.tensor(self.tables.feat_D.tolist()), dim=1)
+        return x * cols
+
+
+class OracleTBE(_MixedPooling, nn.Module):
     def __init__(self, specs, ftm, pooling_mode, device, fused_params):
         super().__init__()
         rows, dims = [s[0] for s in specs], [s[1] for s in specs]
@@ -124,7 +151,7 @@ class _FnInto(torch.autograd.Function):
         ctx.save_for_backward(indices, offsets, psw)
         block, _ = oracle.tbe_forward(mod.tables, indices.numpy(), offsets.numpy(),
                                       psw.numpy() if psw is not None else None, mod.pooling)
-        _scatter_cols(out, torch.from_numpy(block), offs, mod.tables.feat_D.tolist(), stride)
+        _scatter_cols(out, mod._scale_blocks(torch.from_numpy(block), offsets), offs, mod.tables.feat_D.tolist(), stride)
         ctx.mark_dirty(out)
         return out
 
@@ -132,7 +159,7 @@ class _FnInto(torch.autograd.Function):
     def backward(ctx, grad):
         indices, offsets, psw = ctx.saved_tensors
         mod = ctx.mod
-        g = _gather_cols(grad, ctx.offs, mod.tables.feat_D.tolist(), ctx.stride)
+        g = mod._scale_blocks(_gather_cols(grad, ctx.offs, mod.tables.feat_D.tolist(), ctx.stride), offsets).contiguous()
         oracle.tbe_backward(mod.tables, indices.numpy(), offsets.numpy(), g.numpy(), oracle.OPT_EXACT_SGD,
                             mod.optimizer_args.learning_rate, psw.numpy() if psw is not None else None, mod.pooling)
         return (grad,) + (None,) * 7
@@ -155,7 +182,7 @@ class _DenseFnInto(torch.autograd.Function):
         mod._sync_tables()
         block, _ = oracle.tbe_forward(mod.tables, indices.numpy(), offsets.numpy(),
                                       psw.numpy() if psw is not None else None, mod.pooling)
-        _scatter_cols(out, torch.from_numpy(block), offs, mod.tables.feat_D.tolist(), stride)
+        _scatter_cols(out, mod._scale_blocks(torch.from_numpy(block), offsets), offs, mod.tables.feat_D.tolist(), stride)
         ctx.mark_dirty(out)
         return out
 
@@ -163,7 +190,7 @@ class _DenseFnInto(torch.autograd.Function):
     def backward(ctx, grad):
         indices, offsets, psw = ctx.saved_tensors
         mod = ctx.mod
-        g = _gather_cols(grad, ctx.offs, mod.tables.feat_D.tolist(), ctx.stride)
+        g = mod._scale_blocks(_gather_cols(grad, ctx.offs, mod.tables.feat_D.tolist(), ctx.stride), offsets).contiguous()
         gw = [np.zeros((r, d), dtype=np.float32) for r, d in zip(mod.tables.rows, mod.tables.dims)]
         oracle.tbe_backward(mod.tables, indices.numpy(), offsets.numpy(), g.numpy(), oracle.OPT_DENSE_GRAD, 0.0,
                             psw.numpy() if psw is not None else None, mod.pooling, state0=gw)
@@ -171,7 +198,7 @@ class _DenseFnInto(torch.autograd.Function):
         return (grad, flat) + (None,) * 6
 
 
-class OracleDenseTBE(nn.Module):
+class OracleDenseTBE(_MixedPooling, nn.Module):
     """TEST-ONLY stand-in for DenseTableBatchedEmbeddingBagsCodegen (replicated / data-parallel tables):
     `.weights` is a real nn.Parameter so DDP all-reduces its gradient and a dense optimizer steps it."""
 
@@ -180,6 +207,7 @@ class OracleDenseTBE(nn.Module):
         rows, dims = [s[0] for s in specs], [s[1] for s in specs]
         self.tables = oracle.Tables(rows, dims, ftm)
         self.pooling = int(pooling_mode)
+        self.F = len(self.tables.ftm)
         self.weights = nn.Parameter(torch.zeros(sum(r * d for r, d in zip(rows, dims))))
 
     def split_embedding_weights(self):

@@ -58,3 +58,22 @@ def to_dev(a, dtype=None):
     if dtype is not None:
         t = t.to(dtype)
     return t.cuda()
+
+
+def oracle_forward_mixed(tabs, indices, offsets, psw, feat_mean):
+    """Oracle forward with per-FEATURE pooling: SUM and MEAN runs spliced by column block."""
+    out_s, _ = oracle.tbe_forward(tabs, indices, offsets, psw, oracle.POOL_SUM)
+    out_m, _ = oracle.tbe_forward(tabs, indices, offsets, psw, oracle.POOL_MEAN)
+    cols = np.repeat(np.asarray(feat_mean, dtype=bool), np.asarray(tabs.feat_D))
+    return np.where(cols[None, :], out_m, out_s)
+
+
+def oracle_backward_mixed(tabs, indices, offsets, grad, optimizer, lr, psw, feat_mean, **kw):
+    """Oracle backward with per-FEATURE pooling: one SUM pass on the gradient with the MEAN features' blocks zeroed,
+    one MEAN pass on the rest (exact: a table belongs to one pooling type, a zero gradient leaves a row unchanged)."""
+    cols = np.repeat(np.asarray(feat_mean, dtype=bool), np.asarray(tabs.feat_D))
+    g = np.ascontiguousarray(grad, dtype=np.float32)
+    oracle.tbe_backward(tabs, indices, offsets, np.ascontiguousarray(np.where(cols[None, :], 0.0, g), dtype=np.float32), optimizer, lr,
+                        psw, oracle.POOL_SUM, **kw)
+    oracle.tbe_backward(tabs, indices, offsets, np.ascontiguousarray(np.where(cols[None, :], g, 0.0), dtype=np.float32), optimizer, lr,
+                        psw, oracle.POOL_MEAN, **kw)

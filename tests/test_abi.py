@@ -30,7 +30,7 @@ def test_argument_validation_happens_before_any_launch():
     lib = _lib.load()
     rc = lib.tbe_cumsum(None, None, -1, 4, 0, None, 0, None)
     assert rc == -1 and b"n < 0" in lib.tbe_last_error()
-    rc = lib.tbe_forward_pooled_f32(None, None, None, None, 0, 1, 0, None, 0, None, None, 0, None, 0, None, None, None)
+    rc = lib.tbe_forward_pooled_f32(None, None, None, None, 0, 1, 0, None, 0, None, None, 0, None, None, 0, None, None, None)
     assert rc == -1
 
 

@@ -74,8 +74,9 @@ def _build_sharded(W, backend_env, weighted, n_rw, dp_max_rows, offload=False, a
 
     keys = [f"f{i}" for i in range(len(ROWS))]
     from torchrec_amd.modules.embedding_configs import PoolingType
+    # mean: False = SUM, True = MEAN, "mixed" = odd tables MEAN (both pooling types in ONE collection / ONE lookup)
     tables = [EmbeddingBagConfig(name=f"t{i}", embedding_dim=D, num_embeddings=ROWS[i], feature_names=[keys[i]],
-                                 pooling=PoolingType.MEAN if mean else PoolingType.SUM)
+                                 pooling=PoolingType.MEAN if ((i % 2 == 1) if mean == "mixed" else mean) else PoolingType.SUM)
               for i in range(len(ROWS))]
     ebc = EmbeddingBagCollection(tables, is_weighted=weighted, device=torch.device("meta"))
     # offload: the largest table row-wise in host memory behind the HBM row cache (tiny cache: evictions),
@@ -153,9 +154,10 @@ def _worker(rank, W, port, fixed_len, weighted, n_rw, dp_max_rows, ret, offload=
 
 
 def _check_against_oracle(ret, W, fixed_len, weighted, n_rw, dp_max_rows, adagrad=False, mean=False):
+    from _util import oracle_backward_mixed, oracle_forward_mixed
     from oracle import oracle
 
-    pool = oracle.POOL_MEAN if mean else oracle.POOL_SUM
+    feat_mean = [(i % 2 == 1) if mean == "mixed" else bool(mean) for i in range(len(ROWS))]
 
     per_rank, init = _data(W, fixed_len, weighted)
     F, B = len(ROWS), B_LOCAL
@@ -165,7 +167,7 @@ def _check_against_oracle(ret, W, fixed_len, weighted, n_rw, dp_max_rows, adagra
     for r in range(W):
         lengths, vals, wts, _ = per_rank[r]
         offs = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
-        ref, _ = oracle.tbe_forward(tabs, vals, offs, wts, pool)
+        ref = oracle_forward_mixed(tabs, vals, offs, wts, feat_mean)
         if fixed_len == 1 and not weighted:
             np.testing.assert_array_equal(ret[r][0], ref)  # pure gather: bit-exact through the whole exchange
         else:
@@ -195,7 +197,7 @@ def _check_against_oracle(ret, W, fixed_len, weighted, n_rw, dp_max_rows, adagra
             if kinds[f"t{t}"] == "data_parallel":
                 tabs.weights[t][...] = sgd_tabs.weights[t]
     else:
-        oracle.tbe_backward(tabs, g_vals, g_offs, g_grad, oracle.OPT_EXACT_SGD, LR, g_w, pool)
+        oracle_backward_mixed(tabs, g_vals, g_offs, g_grad, oracle.OPT_EXACT_SGD, LR, g_w, feat_mean)
     seen = {t: 0 for t in range(F)}
     for r in range(W):
         for name, shard in ret[r][1].items():
@@ -256,6 +258,15 @@ def test_sharded_world2_mean_pooling_over_row_wise_shards():
     ret = ResultStore()
     mp.spawn(_worker, args=(W, _free_port(), 0, False, 2, 10, ret, False, False, True), nprocs=W, join=True)
     _check_against_oracle(ret, W, 0, False, 2, 10, mean=True)
+
+
+def test_sharded_world2_sum_and_mean_tables_in_one_collection():
+    """Lookup groups without groups: SUM and MEAN tables, table-wise + row-wise + replicated, in ONE
+    sharded collection with ONE fused lookup per rank (per-feature pooling in the kernels) against the oracle."""
+    W = 2
+    ret = ResultStore()
+    mp.spawn(_worker, args=(W, _free_port(), 0, False, 2, 10, ret, False, False, "mixed"), nprocs=W, join=True)
+    _check_against_oracle(ret, W, 0, False, 2, 10, mean="mixed")
 
 
 def test_sharded_world2_with_host_offloaded_tables():

@@ -63,8 +63,10 @@ def _worker(rank, W, port, fixed_len, weighted, n_rw, ret, dp_max_rows=0, mean=F
         per_rank, init = _global_data(W, B_local, fixed_len, weighted)
         keys = [f"f{i}" for i in range(len(ROWS))]
         from torchrec_amd.modules.embedding_configs import PoolingType
+        # mean: False = all SUM, True = all MEAN, "mixed" = odd tables MEAN (both pooling types in ONE collection)
+        is_mean = [(i % 2 == 1) if mean == "mixed" else bool(mean) for i in range(len(ROWS))]
         tables = [EmbeddingBagConfig(name=f"t{i}", embedding_dim=DIMS[i], num_embeddings=ROWS[i], feature_names=[keys[i]],
-                                     pooling=PoolingType.MEAN if mean else PoolingType.SUM)
+                                     pooling=PoolingType.MEAN if is_mean[i] else PoolingType.SUM)
                   for i in range(len(ROWS))]
         ebc = EmbeddingBagCollection(tables, is_weighted=weighted, device=torch.device("meta"))
         plan = EmbeddingShardingPlanner(Topology(W, "cpu"), num_row_wise=n_rw, dp_max_rows=dp_max_rows).plan_tables(tables)
@@ -107,14 +109,16 @@ def _worker(rank, W, port, fixed_len, weighted, n_rw, ret, dp_max_rows=0, mean=F
 @pytest.mark.parametrize("fixed_len,weighted,n_rw,dp_max_rows,mean", [
     (1, False, 1, 0, False), (2, True, 2, 0, False), (0, False, 1, 0, False), (0, True, 0, 0, False),
     (1, False, 5, 0, False), (1, False, 0, 10, False), (0, True, 1, 25, False), (2, False, 0, 100, False),
-    (0, False, 2, 10, True), (3, False, 5, 0, True)])
+    (0, False, 2, 10, True), (3, False, 5, 0, True), (0, False, 2, 10, "mixed"), (0, True, 1, 0, "mixed"), (2, False, 0, 25, "mixed")])
 def test_sharded_equals_unsharded_world2(fixed_len, weighted, n_rw, dp_max_rows, mean):
     """mean=True: MEAN pooling over row-wise shards — every rank divides its partial sum by the FULL bag length
     (all ids travel to every rank, rows outside its block are masked), so the partial pools still add up."""
     from oracle import oracle
 
+    from _util import oracle_backward_mixed, oracle_forward_mixed
+
     W = 2
-    pool = oracle.POOL_MEAN if mean else oracle.POOL_SUM
+    feat_mean = [(i % 2 == 1) if mean == "mixed" else bool(mean) for i in range(len(ROWS))]
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(W, _free_port(), fixed_len, weighted, n_rw, ret, dp_max_rows, mean), nprocs=W, join=True)
@@ -128,7 +132,7 @@ def test_sharded_equals_unsharded_world2(fixed_len, weighted, n_rw, dp_max_rows,
     for r in range(W):
         lengths, vals, wts, grad = per_rank[r]
         offs = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
-        ref, _ = oracle.tbe_forward(tabs, vals, offs, wts, pool)
+        ref = oracle_forward_mixed(tabs, vals, offs, wts, feat_mean)
         np.testing.assert_allclose(ret[r][0], ref, rtol=1e-5, atol=1e-5)
     kinds = ret[0][2]
     assert sum(1 for k in kinds.values() if k == "row_wise") == n_rw
@@ -143,7 +147,7 @@ def test_sharded_equals_unsharded_world2(fixed_len, weighted, n_rw, dp_max_rows,
            if weighted else None)
     g_grad = np.concatenate([per_rank[r][3] for r in range(W)], axis=0) / W
     g_offs = np.concatenate([[0], np.cumsum(g_len)]).astype(np.int64)
-    oracle.tbe_backward(tabs, g_vals, g_offs, g_grad, oracle.OPT_EXACT_SGD, LR, g_w, pool)
+    oracle_backward_mixed(tabs, g_vals, g_offs, g_grad, oracle.OPT_EXACT_SGD, LR, g_w, feat_mean)
     seen_rows = {t: 0 for t in range(F)}
     for r in range(W):
         for name, (w, row0) in ret[r][1].items():

@@ -539,3 +539,35 @@ def test_unimplemented_weight_decay_forms_raise():
                                           weight_decay_mode=WeightDecayMode.L2)
     SplitTableBatchedEmbeddingBagsCodegen(spec, device=dev, optimizer=EmbOptimType.ADAM, weight_decay=1e-5)  # bert4rec_main.py:488-491
     SplitTableBatchedEmbeddingBagsCodegen(spec, device=dev, optimizer=EmbOptimType.EXACT_ROWWISE_ADAGRAD, weight_decay=0.0)
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_sum_and_mean_tables_in_one_module(weighted):
+    """`set_feature_pooling`: SUM and MEAN features share one lookup and one backward (the reference needs one TBE per
+    pooling type + cat: embedding_sharding.py:393-490, embedding_lookup.py:219-253).  Ragged bags incl. empty ones, a
+    table used by two features, different dims; forward and fused row-wise Adagrad against the oracle's per-type runs."""
+    from _util import oracle_backward_mixed, oracle_forward_mixed
+    from fbgemm_gpu.split_embedding_configs import EmbOptimType
+    from fbgemm_gpu.split_table_batched_embeddings_ops import PoolingMode
+
+    rng = np.random.default_rng(21)
+    rows, dims, ftm = [60, 9, 200, 31], [32, 64, 16, 128], [0, 1, 2, 2, 3]
+    feat_mean = [False, True, True, True, False]
+    mod, tabs = build_pair(rows, dims, ftm, 0, EmbOptimType.EXACT_ROWWISE_ADAGRAD, rng, learning_rate=0.1, eps=1e-3)
+    mod.set_feature_pooling([PoolingMode.MEAN if m else PoolingMode.SUM for m in feat_mean])
+    s0 = [np.zeros(r, dtype=np.float32) for r in rows]
+    for step in range(2):
+        indices, offsets, psw = make_inputs(rng, rows, 19, 6, ftm, None, weighted)
+        out = mod(to_dev(indices), to_dev(offsets), to_dev(psw))
+        ref = oracle_forward_mixed(tabs, indices, offsets, psw, feat_mean)
+        np.testing.assert_allclose(out.detach().cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+        grad = rng.standard_normal(ref.shape).astype(np.float32)
+        out.backward(to_dev(grad))
+        torch.cuda.synchronize()
+        oracle_backward_mixed(tabs, indices, offsets, grad, oracle.OPT_EXACT_ROWWISE_ADAGRAD, 0.1, psw, feat_mean, eps=1e-3, state0=s0)
+    for t, w in enumerate(mod.split_embedding_weights()):
+        np.testing.assert_allclose(w.cpu().numpy(), tabs.weights[t], rtol=3e-5, atol=3e-5)
+    for t, st in enumerate(mod.split_optimizer_states()):
+        np.testing.assert_allclose(st[0].cpu().numpy(), s0[t], rtol=3e-5, atol=3e-6)
+    mod.set_feature_pooling([PoolingMode.SUM] * 5)  # uniform again: plain SUM module
+    assert mod.pooling_mode == PoolingMode.SUM and mod._feature_pooling is None

@@ -40,6 +40,7 @@ struct BwdArgs {
   const int64_t* feat_rows;
   const int64_t* feat_row_base;
   const int64_t* feat_window;
+  const int32_t* feat_pooling;  // per-feature SUM / MEAN under pooling_mode MEAN, or nullptr = uniform
   const uint64_t* feat_state0;
   const uint64_t* feat_state1;
   const int64_t* indices;
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(256, MINW) void bwd_update_kernel(BwdArgs a) {
     if (valid_k) {
       if (!FAST) {
         if (a.psw != nullptr) w_k = a.psw[pos_k];
-        if (mean) {
+        if (mean && (a.feat_pooling == nullptr || a.feat_pooling[f_k] == TBE_POOL_MEAN)) {
           const int64_t len = a.offsets[bag_k + 1] - a.offsets[bag_k];
           w_k = w_k / static_cast<float>(len);
         }
@@ -796,7 +797,7 @@ static int backward_entry(
     const int64_t* feat_rows, const int64_t* feat_row_base, const uint64_t* feat_state0,
     const uint64_t* feat_state1, int32_t F, int32_t B, int32_t max_D,
     int32_t key_bits, const int64_t* indices, int64_t N, const int64_t* offsets,
-    const float* per_sample_weights, int32_t pooling_mode, const float* grad_out,
+    const float* per_sample_weights, int32_t pooling_mode, const int32_t* feat_pooling, const float* grad_out,
     int64_t grad_row_stride, tbe_optimizer_args opt, int32_t flags, void* workspace,
     size_t workspace_bytes, int32_t* bounds_errors, const int64_t* feat_window, void* stream, int phase) {
   TBE_REQUIRE(F > 0 && B >= 0 && N >= 0, "tbe_backward_fused_f32: bad sizes");
@@ -850,6 +851,7 @@ static int backward_entry(
   a.feat_rows = feat_rows;
   a.feat_row_base = feat_row_base;
   a.feat_window = feat_window;
+  a.feat_pooling = feat_pooling;
   a.feat_state0 = feat_state0;
   a.feat_state1 = feat_state1;
   a.indices = indices;
@@ -893,11 +895,11 @@ extern "C" int tbe_backward_fused_f32(
     const int64_t* feat_rows, const int64_t* feat_row_base, const uint64_t* feat_state0,
     const uint64_t* feat_state1, int32_t F, int32_t B, int32_t max_D,
     int32_t key_bits, const int64_t* indices, int64_t N, const int64_t* offsets,
-    const float* per_sample_weights, int32_t pooling_mode, const float* grad_out,
+    const float* per_sample_weights, int32_t pooling_mode, const int32_t* feat_pooling, const float* grad_out,
     int64_t grad_row_stride, tbe_optimizer_args opt, int32_t flags, void* workspace,
     size_t workspace_bytes, int32_t* bounds_errors, const int64_t* feat_window, void* stream) {
   return backward_entry(feat_weights, feat_D, feat_out_offset, feat_rows, feat_row_base, feat_state0, feat_state1, F,
-                        B, max_D, key_bits, indices, N, offsets, per_sample_weights, pooling_mode, grad_out,
+                        B, max_D, key_bits, indices, N, offsets, per_sample_weights, pooling_mode, feat_pooling, grad_out,
                         grad_row_stride, opt, flags, workspace, workspace_bytes, bounds_errors, feat_window, stream,
                         kPhasePrepare | kPhaseApply);
 }
@@ -909,7 +911,7 @@ extern "C" int tbe_backward_prepare(const int64_t* feat_rows, const int64_t* fea
                                     void* stream) {
   tbe_optimizer_args opt{};
   return backward_entry(nullptr, nullptr, nullptr, feat_rows, feat_row_base, nullptr, nullptr, F, B, max_D, key_bits,
-                        indices, N, offsets, nullptr, pooling_mode, nullptr, 1, opt, flags & TBE_FLAG_WEIGHTED, workspace,
+                        indices, N, offsets, nullptr, pooling_mode, nullptr, nullptr, 1, opt, flags & TBE_FLAG_WEIGHTED, workspace,
                         workspace_bytes, bounds_errors, feat_window, stream, kPhasePrepare);
 }
 
@@ -918,11 +920,11 @@ extern "C" int tbe_backward_apply_f32(
     const int64_t* feat_rows, const int64_t* feat_row_base, const uint64_t* feat_state0,
     const uint64_t* feat_state1, int32_t F, int32_t B, int32_t max_D,
     int32_t key_bits, const int64_t* indices, int64_t N, const int64_t* offsets,
-    const float* per_sample_weights, int32_t pooling_mode, const float* grad_out,
+    const float* per_sample_weights, int32_t pooling_mode, const int32_t* feat_pooling, const float* grad_out,
     int64_t grad_row_stride, tbe_optimizer_args opt, int32_t flags, void* workspace,
     size_t workspace_bytes, void* stream) {
   return backward_entry(feat_weights, feat_D, feat_out_offset, feat_rows, feat_row_base, feat_state0, feat_state1, F,
-                        B, max_D, key_bits, indices, N, offsets, per_sample_weights, pooling_mode, grad_out,
+                        B, max_D, key_bits, indices, N, offsets, per_sample_weights, pooling_mode, feat_pooling, grad_out,
                         grad_row_stride, opt, flags, workspace, workspace_bytes, nullptr, nullptr, stream, kPhaseApply);
 }
 

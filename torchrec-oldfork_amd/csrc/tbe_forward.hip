@@ -29,6 +29,7 @@ struct FwdArgs {
   const int64_t* feat_out_offset;
   const int64_t* feat_rows;
   const int64_t* feat_window;  // [2F] (first global row, global rows) per feature, or nullptr
+  const int32_t* feat_pooling;  // [F] TBE_POOL_SUM / TBE_POOL_MEAN per feature (with pooling_mode MEAN), or nullptr = uniform
   const int64_t* indices;
   const int64_t* offsets;
   const float* psw;
@@ -89,6 +90,7 @@ __global__ __launch_bounds__(256) void tbe_fwd_short_kernel(FwdArgs a) {
   const int D = a.feat_D[f];
   const int64_t Doff = a.feat_out_offset[f];
   const RowWindow win = load_window(a.feat_rows, a.feat_window, f);
+  const bool mean_f = MEAN && (a.feat_pooling == nullptr || a.feat_pooling[f] == TBE_POOL_MEAN);
   const bool vec = ((D & 3) == 0) && ((Doff & 3) == 0) && ((a.out_stride & 3) == 0) &&
                    ((reinterpret_cast<uintptr_t>(W) & 15) == 0) &&
                    ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0);
@@ -190,14 +192,14 @@ __global__ __launch_bounds__(256) void tbe_fwd_short_kernel(FwdArgs a) {
       const int b = bag0 + p + u * NG + g;
       if (b < a.B && p + u * NG + g < bpw) {
         float scale = 1.f;
-        if (MEAN) scale = len[u] > 0 ? 1.f / static_cast<float>(len[u]) : 0.f;
+        if (mean_f) scale = len[u] > 0 ? 1.f / static_cast<float>(len[u]) : 0.f;
         float* orow = a.out + static_cast<int64_t>(b) * a.out_stride + Doff;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
           const int d = (v * G + gl) * 4;
           if (d < D) {
             float4 r = acc[u][v];
-            if (MEAN) {
+            if (mean_f) {
               r.x *= scale;
               r.y *= scale;
               r.z *= scale;
@@ -231,6 +233,7 @@ __global__ __launch_bounds__(256) void tbe_fwd_long_kernel(FwdArgs a) {
   const int D = a.feat_D[f];
   const int64_t Doff = a.feat_out_offset[f];
   const RowWindow win = load_window(a.feat_rows, a.feat_window, f);
+  const bool mean_f = MEAN && (a.feat_pooling == nullptr || a.feat_pooling[f] == TBE_POOL_MEAN);
   const bool vec = ((D & 3) == 0) && ((Doff & 3) == 0) && ((a.out_stride & 3) == 0) &&
                    ((reinterpret_cast<uintptr_t>(W) & 15) == 0) &&
                    ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0);
@@ -305,14 +308,14 @@ __global__ __launch_bounds__(256) void tbe_fwd_long_kernel(FwdArgs a) {
   }
   if (g == 0) {
     float scale = 1.f;
-    if (MEAN) scale = len > 0 ? 1.f / static_cast<float>(len) : 0.f;
+    if (mean_f) scale = len > 0 ? 1.f / static_cast<float>(len) : 0.f;
     float* orow = a.out + static_cast<int64_t>(b) * a.out_stride + Doff;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       const int d = (v * G + gl) * 4;
       if (d < D) {
         float4 r = acc[v];
-        if (MEAN) {
+        if (mean_f) {
           r.x *= scale;
           r.y *= scale;
           r.z *= scale;
@@ -428,8 +431,8 @@ extern "C" int tbe_forward_pooled_f32(const uint64_t* feat_weights, const int32_
                                       int32_t F, int32_t B, int32_t max_D,
                                       const int64_t* indices, int64_t N, const int64_t* offsets,
                                       const float* per_sample_weights, int32_t pooling_mode,
-                                      float* out, int64_t out_row_stride, int32_t* bounds_errors,
-                                      const int64_t* feat_window, void* stream) {
+                                      const int32_t* feat_pooling, float* out, int64_t out_row_stride,
+                                      int32_t* bounds_errors, const int64_t* feat_window, void* stream) {
   TBE_REQUIRE(F > 0 && B >= 0 && N >= 0, "tbe_forward_pooled_f32: bad sizes F=%d B=%d N=%lld", F, B,
               (long long)N);
   TBE_REQUIRE(pooling_mode == TBE_POOL_SUM || pooling_mode == TBE_POOL_MEAN,
@@ -441,7 +444,7 @@ extern "C" int tbe_forward_pooled_f32(const uint64_t* feat_weights, const int32_
               "tbe_forward_pooled_f32: null pointer");
   TBE_REQUIRE(N == 0 || indices != nullptr, "tbe_forward_pooled_f32: null indices");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  FwdArgs a{feat_weights, feat_D, feat_out_offset, feat_rows, feat_window, indices, offsets, per_sample_weights,
+  FwdArgs a{feat_weights, feat_D, feat_out_offset, feat_rows, feat_window, feat_pooling, indices, offsets, per_sample_weights,
             out, bounds_errors, out_row_stride, N, F, B, 64};
   // small launches: 4x more waves (16 bags each) keep more row reads in flight per CU
   if (static_cast<int64_t>(F) * B < (static_cast<int64_t>(1) << 19)) a.bags_per_wave = 16;

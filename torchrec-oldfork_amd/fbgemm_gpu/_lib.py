@@ -56,7 +56,7 @@ SIGNATURES = {
     "tbe_forward_pooled_f32": (
         ctypes.c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p, c_i64,
-         c_void_p, c_void_p, c_i32, c_void_p, c_i64, c_void_p, c_void_p, c_void_p],
+         c_void_p, c_void_p, c_i32, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p],
     ),
     "tbe_forward_nobag_f32": (
         ctypes.c_int,
@@ -67,7 +67,7 @@ SIGNATURES = {
     "tbe_backward_fused_f32": (
         ctypes.c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32,
-         c_i32, c_i32, c_void_p, c_i64, c_void_p, c_void_p, c_i32, c_void_p, c_i64, OptimizerArgs,
+         c_i32, c_i32, c_void_p, c_i64, c_void_p, c_void_p, c_i32, c_void_p, c_void_p, c_i64, OptimizerArgs,
          c_i32, c_void_p, c_size, c_void_p, c_void_p, c_void_p],
     ),
     "tbe_backward_prepare": (
@@ -85,7 +85,7 @@ SIGNATURES = {
     "tbe_backward_apply_f32": (
         ctypes.c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32,
-         c_i32, c_i32, c_void_p, c_i64, c_void_p, c_void_p, c_i32, c_void_p, c_i64, OptimizerArgs,
+         c_i32, c_i32, c_void_p, c_i64, c_void_p, c_void_p, c_i32, c_void_p, c_void_p, c_i64, OptimizerArgs,
          c_i32, c_void_p, c_size, c_void_p],
     ),
     "tbe_cache_prefetch_workspace_bytes": (c_size, [c_i64, c_i32]),

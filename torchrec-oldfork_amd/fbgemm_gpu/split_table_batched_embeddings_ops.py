@@ -116,6 +116,7 @@ class _Layout:
         self.feat_out_offset = None
         self.feat_rows = None
         self.feat_window = None  # [2F] (first global row, global rows) of row-wise shards, or None
+        self.feat_pooling = None  # [F] per-feature SUM / MEAN, or None = uniform
         self.feat_row_base = None
         self.feat_state0 = None
         self.feat_state1 = None
@@ -235,7 +236,7 @@ class _RowCache:
                 r.feat_window = r.feat_window.view(-1)
             r.feat_row_base = lay.feat_row_base.clone()
             r.feat_row_base[cf] = self.m.total_rows
-            r.feat_D, r.feat_out_offset = lay.feat_D, lay.feat_out_offset
+            r.feat_D, r.feat_out_offset, r.feat_pooling = lay.feat_D, lay.feat_out_offset, lay.feat_pooling
             r.feat_state0, r.feat_state1 = lay.feat_state0, lay.feat_state1
             if self.rowwise_state:
                 r.feat_state0 = lay.feat_state0.clone()
@@ -363,6 +364,7 @@ class _TBEBase(nn.Module):
         self._cache: Optional[_RowCache] = None
         self._bounds_errors: Optional[torch.Tensor] = None
         self._row_windows = None  # see set_row_windows
+        self._feature_pooling = None  # see set_feature_pooling
         self._side_stream = None
         # sort the batch's row keys on a side stream during forward (see _prepare_backward)
         # "auto": only for lookups small enough to leave CUs idle (measured on MI355X: at 1.7 M ids the
@@ -435,7 +437,7 @@ class _TBEBase(nn.Module):
     def _real_layout(self) -> _Layout:
         self._ensure_pinned()
         s0, s1 = self._state_ptrs()
-        key = (self._storage_key(), tuple(s0 or ()), tuple(s1 or ()), self._row_windows)
+        key = (self._storage_key(), tuple(s0 or ()), tuple(s1 or ()), self._row_windows, self._feature_pooling)
         lay = self._layout
         if lay.key == key:
             return lay
@@ -454,6 +456,7 @@ class _TBEBase(nn.Module):
         lay.feat_D = i32(self.feat_D)
         lay.feat_out_offset = i64(self.D_offsets[:-1])
         lay.feat_rows = i64([self.rows_per_table[t] for t in ftm])
+        lay.feat_pooling = i32(self._feature_pooling) if self._feature_pooling is not None else None
         lay.feat_window = None
         if self._row_windows is not None:
             lay.feat_window = i64([x for pair in zip(*self._row_windows) for x in pair])
@@ -462,6 +465,26 @@ class _TBEBase(nn.Module):
         lay.feat_state1 = i64([s1[t] for t in ftm]) if s1 is not None else None
         lay.key = key
         return lay
+
+    def set_feature_pooling(self, modes: Optional[List["PoolingMode"]]) -> None:
+        """Per-FEATURE pooling (SUM / MEAN) inside one module: tables of both pooling types share one lookup and one
+        backward (the reference builds one TBE per pooling type and concatenates the results:
+        embedding_sharding.py:393-490, embedding_lookup.py:219-253).  The module's pooling_mode becomes MEAN; features
+        listed as SUM are not divided.  None restores the uniform mode given at construction."""
+        if modes is None:
+            self._feature_pooling = None
+            self.pooling_mode = getattr(self, "_ctor_pooling_mode", self.pooling_mode)
+            return
+        modes = [PoolingMode(int(m)) for m in modes]
+        if len(modes) != self.F or any(m == PoolingMode.NONE for m in modes) or self.pooling_mode == PoolingMode.NONE:
+            raise ValueError("set_feature_pooling: one of SUM / MEAN per feature, on a pooled module")
+        if not hasattr(self, "_ctor_pooling_mode"):
+            self._ctor_pooling_mode = self.pooling_mode
+        if all(m == modes[0] for m in modes):
+            self._feature_pooling, self.pooling_mode = None, modes[0]
+            return
+        self._feature_pooling = tuple(int(m) for m in modes)
+        self.pooling_mode = PoolingMode.MEAN
 
     def set_row_windows(self, first_rows: Optional[List[int]], global_rows: Optional[List[int]] = None) -> None:
         """Row-wise shards fed with un-bucketized GLOBAL ids: feature f's table holds global rows
@@ -584,7 +607,7 @@ class _TBEBase(nn.Module):
                 lib.tbe_forward_pooled_f32(ptr(lay.feat_weights), ptr(lay.feat_D),
                                            ptr(out_off), ptr(lay.feat_rows), self.F, B,
                                            self.max_D, ptr(indices), N, ptr(offsets),
-                                           ptr(per_sample_weights), int(self.pooling_mode), ptr(out),
+                                           ptr(per_sample_weights), int(self.pooling_mode), ptr(lay.feat_pooling), ptr(out),
                                            stride, self._errors_ptr(), ptr(lay.feat_window), stream_ptr(dev)),
                 "tbe_forward_pooled_f32",
             )
@@ -657,7 +680,7 @@ class _TBEBase(nn.Module):
                                                ptr(lay.feat_rows), ptr(lay.feat_row_base), ptr(feat_state0),
                                                ptr(lay.feat_state1), self.F, B, self.max_D, self.key_bits,
                                                ptr(indices), N, ptr(offsets), ptr(per_sample_weights),
-                                               int(self.pooling_mode), ptr(grad_out), stride, opt, flags,
+                                               int(self.pooling_mode), ptr(lay.feat_pooling), ptr(grad_out), stride, opt, flags,
                                                ptr(ws), ws.numel(), stream_ptr(dev)),
                     "tbe_backward_apply_f32",
                 )
@@ -672,7 +695,7 @@ class _TBEBase(nn.Module):
                                            ptr(lay.feat_row_base), ptr(feat_state0),
                                            ptr(lay.feat_state1), self.F, B,
                                            self.max_D, self.key_bits, ptr(indices), N, ptr(offsets),
-                                           ptr(per_sample_weights), int(self.pooling_mode),
+                                           ptr(per_sample_weights), int(self.pooling_mode), ptr(lay.feat_pooling),
                                            ptr(grad_out), stride, opt, flags, ptr(ws), ws.numel(),
                                            self._errors_ptr(), ptr(lay.feat_window), stream_ptr(dev)),
                 "tbe_backward_fused_f32",

@@ -282,9 +282,9 @@ class ShardedEmbeddingBagCollection(nn.Module):
         self._is_weighted = module.is_weighted
         cfgs = module.embedding_bag_configs
         self._embedding_bag_configs = cfgs
-        poolings = {c.pooling for c in cfgs}
-        if len(poolings) != 1:
-            raise ValueError("all tables must share one pooling type")
+        # tables of different pooling types (and dims, and placements) share ONE lookup per rank: pooling is
+        # per-feature metadata of the kernels, not a reason for a second module + cat (the reference groups by
+        # pooling / data type / compute kernel: embedding_sharding.py:393-490, embedding_lookup.py:219-253)
         # ---- global feature list, in the collection's output order -----------------------------
         self._feature_names: List[str] = []
         g_table: List[int] = []
@@ -373,11 +373,14 @@ class ShardedEmbeddingBagCollection(nn.Module):
         if self._local_tables:
             self._emb_module = factory(
                 [(max(lt.local_rows, 0), lt.cfg.embedding_dim, lt.compute_kernel) for lt in self._local_tables],
-                ftm_local * W, pooling_type_to_pooling_mode(cfgs[0].pooling), dev, fused_params)
+                ftm_local * W, pooling_type_to_pooling_mode(self._local_tables[ftm_local[0]].cfg.pooling), dev, fused_params)
             if self._exchange:
                 self._emb_module.set_a2a_output_layout(W)
             if self._has_rw:
                 self._emb_module.set_row_windows(win_first * W, win_global * W)
+            local_pooling = [pooling_type_to_pooling_mode(self._local_tables[i].cfg.pooling) for i in ftm_local]
+            if len(set(local_pooling)) > 1:
+                self._emb_module.set_feature_pooling(local_pooling * W)
             self._init_parameters()
             self._optim = EmbeddingFusedOptimizer(self._emb_module, [lt.cfg.name for lt in self._local_tables],
                                                   key_prefix="embedding_bags.")
@@ -394,8 +397,11 @@ class ShardedEmbeddingBagCollection(nn.Module):
                     self._dp_table_ids.append(g_table[g])
             dp_ftm = [self._dp_table_ids.index(g_table[g]) for g in self._dp_feats]
             dpf = dp_tbe_factory or _default_dp_tbe_factory
+            dp_pooling = [pooling_type_to_pooling_mode(cfgs[g_table[g]].pooling) for g in self._dp_feats]
             self._dp_module = dpf([(cfgs[t].num_embeddings, cfgs[t].embedding_dim) for t in self._dp_table_ids], dp_ftm,
-                                  pooling_type_to_pooling_mode(cfgs[0].pooling), dev)
+                                  dp_pooling[0], dev)
+            if len(set(dp_pooling)) > 1:
+                self._dp_module.set_feature_pooling(dp_pooling)
             self._dp_module._owned_by_sharded_module = True  # its weights load / save as embedding_bags.<t>.weight
             for t, w in zip(self._dp_table_ids, self._dp_module.split_embedding_weights()):
                 w.uniform_(cfgs[t].get_weight_init_min(), cfgs[t].get_weight_init_max())
