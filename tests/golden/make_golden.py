@@ -201,6 +201,9 @@ def main():
             pooling="mean")
     gen_ebc(torchrec, "long_bags", 5, rows=[200, 13], dims=[128, 64], B=9, max_len=40, weighted=False,
             pooling="sum")
+    # the headline geometry (D = 128, pooling factor 1: a pure gather) on 10 tables incl. tiny ones
+    gen_ebc(torchrec, "l1_d128", 6, rows=[300, 3, 100, 17, 62, 4, 97, 128, 220, 10], dims=[128] * 10, B=64, max_len=1,
+            weighted=False, pooling="sum", fixed_len=1)
     gen_bucketize(torchrec)
     gen_recat(torchrec)
     gen_dlrm(torchrec)

@@ -571,3 +571,57 @@ def test_sum_and_mean_tables_in_one_module(weighted):
         np.testing.assert_allclose(st[0].cpu().numpy(), s0[t], rtol=3e-5, atol=3e-6)
     mod.set_feature_pooling([PoolingMode.SUM] * 5)  # uniform again: plain SUM module
     assert mod.pooling_mode == PoolingMode.SUM and mod._feature_pooling is None
+
+
+@pytest.mark.parametrize("B", [4096, 65536], ids=["config2_batch4096", "headline_batch65536"])
+def test_full_size_criteo_26_tables_properties(B):
+    """The REAL workload (BASELINE configs 2 and the headline): all 26 Criteo-1TB tables at full size (177.9 M rows,
+    84.85 GiB fp32 in HBM), pooling factor 1, D = 128 — with assertions, not only timed.  Size-independent properties,
+    every table, bit-exact:
+      * forward is a pure gather: output block (b, t) == row ids[t, b] of table t;
+      * backward with an all-ones gradient and lr = 0.5 (lr * count is exact in fp32) moves every touched row by exactly
+        -lr * multiplicity and leaves every other row alone (checked on the touched rows + a random sample of the rest)."""
+    from fbgemm_gpu.split_table_batched_embeddings_ops import (
+        ComputeDevice, EmbeddingLocation, SplitTableBatchedEmbeddingBagsCodegen)
+
+    rows = [45833188, 36746, 17245, 7413, 20243, 3, 7114, 1441, 62, 29275261, 1572176, 345138, 10, 2209, 11267, 128, 4, 974, 14,
+            48937457, 11316796, 40094537, 452104, 12606, 104, 35]
+    dev = torch.device("cuda", 0)
+    free, _ = torch.cuda.mem_get_info(dev)
+    if free < 110 * 2**30:
+        pytest.skip("needs ~100 GiB of free HBM")
+    D, T, lr = 128, len(rows), 0.5
+    mod = SplitTableBatchedEmbeddingBagsCodegen([(r, D, EmbeddingLocation.DEVICE, ComputeDevice.CUDA) for r in rows],
+                                                learning_rate=lr, device=dev)
+    ws = mod.split_embedding_weights()
+    assert sum(w.numel() for w in ws) * 4 == 177944275 * 512
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + B)
+    for w in ws:
+        w.uniform_(-1.0, 1.0, generator=g)
+    idx = torch.cat([torch.randint(0, r, (B,), generator=g, device=dev, dtype=torch.int64) for r in rows])
+    off = torch.arange(T * B + 1, dtype=torch.int64, device=dev)
+    out = mod(idx, off)
+    assert tuple(out.shape) == (B, T * D)
+    before_rows, probe_ids, probe_before = [], [], []
+    for t in range(T):
+        ids = idx[t * B:(t + 1) * B]
+        rows_t = ws[t][ids]
+        assert torch.equal(out[:, t * D:(t + 1) * D], rows_t), f"table {t}: forward is not a pure gather"
+        before_rows.append(rows_t.clone())
+        p = torch.randint(0, rows[t], (min(rows[t], 4096),), generator=g, device=dev)
+        probe_ids.append(p)
+        probe_before.append(ws[t][p].clone())
+    out.backward(torch.ones_like(out))
+    torch.cuda.synchronize()
+    assert mod.bounds_check_errors() == 0
+    for t in range(T):
+        ids = idx[t * B:(t + 1) * B]
+        uniq, inv, cnt = torch.unique(ids, return_inverse=True, return_counts=True)
+        mult = cnt[inv].float()                                   # multiplicity of every lookup's row
+        expect = before_rows[t] - lr * mult[:, None]              # exact: lr * count is a dyadic rational < 2^24
+        assert torch.equal(ws[t][ids], expect), f"table {t}: touched rows did not move by -lr * multiplicity"
+        touched = torch.zeros(rows[t], dtype=torch.bool, device=dev)
+        touched[uniq] = True
+        keep = ~touched[probe_ids[t]]
+        assert torch.equal(ws[t][probe_ids[t]][keep], probe_before[t][keep]), f"table {t}: an untouched row changed"

@@ -15,6 +15,8 @@ from typing import Dict, List, Optional, Tuple
 
 import torch
 
+import fbgemm_gpu  # noqa: F401  registers torch.ops.fbgemm.* (the reference loads the op library here: jagged_tensor.py:18-24)
+
 
 def _host_cumsum(x: List[int]) -> List[int]:
     out = [0] * (len(x) + 1)
