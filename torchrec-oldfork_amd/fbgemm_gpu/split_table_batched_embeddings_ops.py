@@ -613,6 +613,26 @@ class _TBEBase(nn.Module):
             )
         return out
 
+    def _prepare_or_defer(self, ctx, indices, offsets, B: int, weighted: bool):
+        """The side-stream sort of this lookup's backward: started now, or — with `defer_backward_sort` — when the
+        owner calls launch_deferred_backward_sort() (a model that knows its schedule puts the sort next to its
+        MFMA-bound GEMMs instead of next to HBM-bound kernels: DESIGN.md §3)."""
+        if not getattr(self, "defer_backward_sort", False):
+            return self._prepare_backward(indices, offsets, B, weighted)
+        self._deferred_sort = (ctx, indices, offsets, B, weighted)
+        return None
+
+    def launch_deferred_backward_sort(self) -> bool:
+        """Starts the deferred sort of the latest forward (if any) on the side stream, ordered after the work
+        enqueued so far on the current stream.  Without this call the backward sorts inline (fused call)."""
+        d = getattr(self, "_deferred_sort", None)
+        if d is None:
+            return False
+        self._deferred_sort = None
+        ctx, indices, offsets, B, weighted = d
+        ctx.prepared = self._prepare_backward(indices, offsets, B, weighted)
+        return True
+
     def _prepare_backward(self, indices, offsets, B: int, weighted: bool = False):
         """Enqueues the gradient-independent half of backward (linearize + stable sort of the row
         keys) on a side stream, right after the forward kernel, so that it overlaps whatever the
@@ -710,8 +730,7 @@ class _FusedLookupInto(torch.autograd.Function):
         ctx.module, ctx.B, ctx.layout = module, B, (out_off, stride)
         ctx.save_for_backward(indices, offsets, per_sample_weights)
         module._forward_impl(indices, offsets, per_sample_weights, B, into=(out, out_off, stride))
-        ctx.prepared = (module._prepare_backward(indices, offsets, B, per_sample_weights is not None)
-                        if prepare else None)
+        ctx.prepared = module._prepare_or_defer(ctx, indices, offsets, B, per_sample_weights is not None) if prepare else None
         ctx.mark_dirty(out)
         return out
 
@@ -757,8 +776,7 @@ class _FusedLookup(torch.autograd.Function):
         ctx.B = B
         ctx.save_for_backward(indices, offsets, per_sample_weights)
         out = module._forward_impl(indices, offsets, per_sample_weights, B)
-        ctx.prepared = (module._prepare_backward(indices, offsets, B, per_sample_weights is not None)
-                        if prepare else None)
+        ctx.prepared = module._prepare_or_defer(ctx, indices, offsets, B, per_sample_weights is not None) if prepare else None
         return out
 
     @staticmethod

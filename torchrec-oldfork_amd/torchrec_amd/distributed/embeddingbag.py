@@ -407,6 +407,15 @@ class ShardedEmbeddingBagCollection(nn.Module):
                 w.uniform_(cfgs[t].get_weight_init_min(), cfgs[t].get_weight_init_max())
             self._dp_out_off = torch.tensor([out_col[g] for g in self._dp_feats], dtype=torch.int64, device=dev)
 
+    def defer_backward_sort(self, on: bool = True) -> None:
+        """Lets the caller choose when the fused lookup's backward sort starts (launch_deferred_backward_sort)."""
+        if self._emb_module is not None:
+            self._emb_module.defer_backward_sort = bool(on)
+
+    def launch_deferred_backward_sort(self) -> bool:
+        m = self._emb_module
+        return bool(m is not None and hasattr(m, "launch_deferred_backward_sort") and m.launch_deferred_backward_sort())
+
     def set_output_buffer(self, buf: Optional[torch.Tensor]) -> None:
         """A persistent float32 buffer of B_local * sum(D) elements that receives the pooled output of every
         step with that batch size (instead of a fresh allocation) — e.g. the static input of a HIP-graph

@@ -3,6 +3,7 @@ examples/dlrm/modules/dlrm_train.py).  Module and parameter names follow the ref
 state_dict keys are interchangeable (`dense_arch.model._mlp.0._linear.weight`,
 `over_arch.model.1.bias`, ...).  The dense MLPs and the dot interaction are the only MFMA
 users of the path (rocBLAS/hipBLASLt fp32 GEMMs)."""
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -42,6 +43,22 @@ class SparseArch(nn.Module):
     @property
     def sparse_feature_names(self) -> List[str]:
         return self._sparse_feature_names
+
+
+# Where the embedding backward's side-stream sort starts: "lookup" (default) = right behind the lookup kernel, beside the
+# bottom MLP (measured best at N = 1: 7.62 M samples/s); "head" = behind the interaction forward, beside the over-arch
+# GEMMs (7.58 M: the GEMMs fill every CU, the sort's launches trickle in).  DESIGN.md §3.
+_SORT_PLACEMENT = os.environ.get("TORCHREC_AMD_SORT_PLACEMENT", "lookup")
+
+
+def _sort_hooks(ebc: nn.Module):
+    """(defer, launch) callables of a collection that lets its caller place the backward sort, or (None, None)."""
+    if _SORT_PLACEMENT != "head":
+        return None, None
+    inner = getattr(ebc, "sharded", ebc)  # the train pipeline wraps sharded collections (train_pipeline._PipelinedEBC)
+    if hasattr(inner, "defer_backward_sort") and hasattr(inner, "launch_deferred_backward_sort"):
+        return inner.defer_backward_sort, inner.launch_deferred_backward_sort
+    return None, None
 
 
 class DenseArch(nn.Module):
@@ -158,10 +175,18 @@ class DLRM(nn.Module):
         # The reference runs dense_arch, then sparse_arch (models/dlrm.py:400-401).  Here the lookup and
         # the pooled all-to-all are issued first so that the exchange overlaps the bottom MLP on the
         # collective's own HIP stream; the two branches are independent, results are identical.
+        # The embedding backward's sort (side stream, gradient-independent) is started AFTER the HBM-bound part of the
+        # forward (lookup, interaction) and runs beside the over-arch GEMMs, which are MFMA-bound and leave the
+        # vector units, LDS and memory queues it needs mostly idle.
+        defer, launch = _sort_hooks(self.sparse_arch.embedding_bag_collection)
+        if defer is not None:
+            defer(self.training and torch.is_grad_enabled())
         pending = self.sparse_arch.start(sparse_features)
         embedded_dense = self.dense_arch(dense_features)
         embedded_sparse = self.sparse_arch.finish(pending)
         concatenated = self.inter_arch(dense_features=embedded_dense, sparse_features=embedded_sparse)
+        if launch is not None:
+            launch()
         return self.over_arch(concatenated)
 
 
@@ -319,9 +344,14 @@ class DLRMTrain(nn.Module):
         if (g is not None and self.training and torch.is_grad_enabled()
                 and batch.dense_features.shape[0] == g[0] and batch.dense_features.is_cuda):
             _, g_dense, g_head = g
+            defer, launch = _sort_hooks(self.model.sparse_arch.embedding_bag_collection)
+            if defer is not None:
+                defer(True)
             pending = self.model.sparse_arch.start(batch.sparse_features)
             embedded_dense = g_dense(batch.dense_features)
             embedded_sparse = self.model.sparse_arch.finish(pending)
+            if launch is not None:
+                launch()  # beside the head segment (interaction + over arch), after the lookup and the exchange
             loss, logits = g_head(embedded_dense, embedded_sparse, batch.labels.float())
             return loss, (loss.detach(), logits.detach(), batch.labels.detach())
         logits = self.model(batch.dense_features, batch.sparse_features).squeeze(-1)
