@@ -54,6 +54,20 @@ def set_gradient_division(val: bool) -> None:
     GRADIENT_DIVISION = val
 
 
+def _gather_rows(mat: torch.Tensor, order: List[int]) -> torch.Tensor:
+    """Rows `order` of a [keys, B * L] id / weight matrix as one contiguous [len(order), B * L] block.  A cat of row
+    views (one batched-copy launch); torch.index_select picks a per-element kernel for this shape that needs 87 us for
+    26 x 8192 ids (rocprof, MI355X) where the copy takes ~5."""
+    if not order:
+        return mat.new_empty((0, mat.shape[1]))
+    runs, start = [], 0  # consecutive rows travel as one slice
+    for i in range(1, len(order) + 1):
+        if i == len(order) or order[i] != order[i - 1] + 1:
+            runs.append(mat[order[start]:order[i - 1] + 1])
+            start = i
+    return runs[0] if len(runs) == 1 else torch.cat(runs, dim=0)
+
+
 def _default_dp_tbe_factory(specs, ftm, pooling_mode, device):
     from fbgemm_gpu.split_table_batched_embeddings_ops import DenseTableBatchedEmbeddingBagsCodegen
 
@@ -564,8 +578,8 @@ class ShardedEmbeddingBagCollection(nn.Module):
         if fixed is not None and len(set(fixed)) == 1 and fixed[0] > 0:
             L = fixed[0]
             nkeys = len(keys)
-            v = features.values().view(nkeys, B * L).index_select(0, order_t).view(-1)
-            w = weights.view(nkeys, B * L).index_select(0, order_t).view(-1) if weights is not None else None
+            v = _gather_rows(features.values().view(nkeys, B * L), order).reshape(-1)
+            w = _gather_rows(weights.view(nkeys, B * L), order).reshape(-1) if weights is not None else None
             ck2 = ("dpoff", B, L)
             offs = self._kjt_cache.get(ck2)
             if offs is None:
@@ -588,8 +602,8 @@ class ShardedEmbeddingBagCollection(nn.Module):
                 send_v = features.values().view(nkeys, B * L)
                 send_w = weights.view(nkeys, B * L) if weights is not None else None
             else:
-                send_v = features.values().view(nkeys, B * L).index_select(0, order_t)
-                send_w = weights.view(nkeys, B * L).index_select(0, order_t) if weights is not None else None
+                send_v = _gather_rows(features.values().view(nkeys, B * L), order)
+                send_w = _gather_rows(weights.view(nkeys, B * L), order) if weights is not None else None
             in_splits = [n * B * L for n in self._send_feats_per_rank]
             out_splits = [self._F_local * B * L] * W
             if self._exchange:
