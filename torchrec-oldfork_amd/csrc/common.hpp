@@ -36,7 +36,8 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 bool profile_enabled();
 void profile_begin(int slot, hipStream_t st, hipEvent_t* after);
 void profile_end(hipEvent_t after, hipStream_t st);
-unsigned long long* profile_unique_rows_counter();  // device counter, nullptr unless profiling
+constexpr int kProfileRowSlots = 64;  // counters of 128 B each
+unsigned long long* profile_unique_rows_counter();  // kProfileRowSlots device counters (one per 128 B), nullptr unless profiling
 struct ProfileSpan {
   hipEvent_t after = nullptr;
   hipStream_t st;

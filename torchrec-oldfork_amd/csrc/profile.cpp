@@ -9,6 +9,8 @@
 
 #include "../../include/tbe_hip.h"
 
+static constexpr int kProfileRowSlots = 64;  // must equal tbe::kProfileRowSlots (common.hpp)
+
 namespace tbe {
 
 struct Span {
@@ -51,8 +53,9 @@ void profile_end(hipEvent_t after, hipStream_t st) {
 extern "C" int tbe_profile_enable(int32_t on) {
   std::lock_guard<std::mutex> lk(tbe::g_mu);
   if (on && tbe::g_rows_dev == nullptr) {
-    if (hipMalloc(&tbe::g_rows_dev, sizeof(unsigned long long)) != hipSuccess) return TBE_ERR_LAUNCH;
-    (void)hipMemset(tbe::g_rows_dev, 0, sizeof(unsigned long long));
+    // kProfileRowSlots counters, one per 128-B line: the update kernel's workgroups add to different lines
+    if (hipMalloc(&tbe::g_rows_dev, kProfileRowSlots * 128) != hipSuccess) return TBE_ERR_LAUNCH;
+    (void)hipMemset(tbe::g_rows_dev, 0, kProfileRowSlots * 128);
   }
   tbe::g_on = on != 0;
   return TBE_OK;
@@ -85,10 +88,12 @@ extern "C" int tbe_profile_read_rows(int64_t* rows_updated) {
   if (!rows_updated) return TBE_ERR_INVALID_ARGUMENT;
   *rows_updated = 0;
   if (tbe::g_rows_dev == nullptr) return TBE_OK;
-  unsigned long long v = 0;
+  std::vector<unsigned long long> v(kProfileRowSlots * 16);
   if (hipDeviceSynchronize() != hipSuccess) return TBE_ERR_LAUNCH;
-  if (hipMemcpy(&v, tbe::g_rows_dev, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return TBE_ERR_LAUNCH;
-  (void)hipMemset(tbe::g_rows_dev, 0, sizeof(v));
-  *rows_updated = static_cast<int64_t>(v);
+  if (hipMemcpy(v.data(), tbe::g_rows_dev, kProfileRowSlots * 128, hipMemcpyDeviceToHost) != hipSuccess) return TBE_ERR_LAUNCH;
+  (void)hipMemset(tbe::g_rows_dev, 0, kProfileRowSlots * 128);
+  unsigned long long tot = 0;
+  for (int i = 0; i < kProfileRowSlots; ++i) tot += v[i * 16];
+  *rows_updated = static_cast<int64_t>(tot);
   return TBE_OK;
 }

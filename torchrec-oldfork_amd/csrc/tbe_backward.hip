@@ -461,7 +461,14 @@ __global__ __launch_bounds__(256, MINW) void bwd_update_kernel(BwdArgs a) {
     }
     if (gl == 0 && is_origin) a.origin_list[atomicAdd(a.origin_count, 1)] = static_cast<int32_t>(chunk);
     nrows += is_origin;
-    if (a.unique_rows != nullptr && gl == 0 && nrows > 0) atomicAdd(a.unique_rows, static_cast<unsigned long long>(nrows));
+  }
+  if (a.unique_rows != nullptr) {  // profiling only: one add per WAVE, spread over kProfileRowSlots cache lines
+    int wave_rows = (active && gl == 0) ? nrows : 0;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) wave_rows += __shfl_xor(wave_rows, o, kWave);
+    if (lane == 0 && wave_rows > 0)
+      atomicAdd(a.unique_rows + ((blockIdx.x * 4 + (threadIdx.x >> 6)) % kProfileRowSlots) * 16,
+                static_cast<unsigned long long>(wave_rows));
   }
 }
 
@@ -642,9 +649,9 @@ __global__ __launch_bounds__(256) void bwd_fixup_kernel(BwdArgs a) {
 
 static int pick_chunk(int64_t N) {
   static const int forced = [] {
-    const char* e = getenv("TBE_BWD_CHUNK");  // tuning knob (multiple of 32 in [32, 1024])
+    const char* e = getenv("TBE_BWD_CHUNK");  // tuning knob (multiple of 8 in [8, 1024])
     const int v = e ? atoi(e) : 0;
-    return (v >= 32 && v <= 1024 && v % 32 == 0) ? v : 0;
+    return (v >= 8 && v <= 1024 && v % 8 == 0) ? v : 0;
   }();
   if (forced) return forced;
   int64_t c = (N + 16383) / 16384;
