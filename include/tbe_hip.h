@@ -372,11 +372,16 @@ int tbe_pooled_exchange_pack(const float* grad, float* send, const int32_t* feat
  *   out[b] = [dense[b] | <X_i, X_j> for i < j in torch.triu_indices(F+1, F+1, 1) order],
  *   X = [dense[b]; sparse[b]].
  * forward: 1 <= F <= 31, D in {16, 32, 64, 128, 256}.  backward: F <= 27, D in {16, 32, 64, 128}.
+ * out_row_stride / grad_row_stride (elements, >= D + (F+1)F/2): rows of `out` / `grad_out` may be padded.  The
+ * reference's dense rows (stride 479 floats at F = 26, D = 128) are not 16-B aligned; with a stride that is a
+ * multiple of 4 and leaves room for the pair block rounded up to 4 (480) the forward stores 16 B per lane and
+ * writes the pad columns as zeros, and the GEMMs of the next layer read aligned rows (lda = 480, K = 479).
  * ---------------------------------------------------------------------------------- */
 int tbe_dlrm_interaction_forward_f32(const float* dense, const float* sparse, int32_t B,
-                                     int32_t F, int32_t D, float* out, void* stream);
+                                     int32_t F, int32_t D, float* out, int64_t out_row_stride,
+                                     void* stream);
 int tbe_dlrm_interaction_backward_f32(const float* dense, const float* sparse,
-                                      const float* grad_out, int32_t B, int32_t F, int32_t D,
+                                      const float* grad_out, int64_t grad_row_stride, int32_t B, int32_t F, int32_t D,
                                       float* grad_dense, float* grad_sparse, void* stream);
 
 /* ReLU backward + bias gradient of one MLP layer in one pass (torchrec/modules/mlp.py:14-170 Perceptron

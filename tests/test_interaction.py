@@ -69,8 +69,11 @@ def test_dlrm_model_state_dict_keys_and_logits_match_reference_golden():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("pad_rows", [False, True], ids=["dense_rows", "padded_rows"])
 @pytest.mark.parametrize("B,F,D", [(65, 26, 128), (1, 26, 128), (300, 2, 16), (17, 7, 32), (9, 27, 64), (1030, 26, 128)])
-def test_hip_interaction_bit_exact_vs_oracle(B, F, D):
+def test_hip_interaction_bit_exact_vs_oracle(B, F, D, pad_rows):
+    """pad_rows: the output is a [B, D + P] view of a buffer whose rows are padded to a multiple of 4 floats (16-B
+    stores); the gradient comes back both as a dense tensor and as a row-padded view."""
     from torchrec_amd.models.dlrm import InteractionArch
 
     rng = np.random.default_rng(B + F + D)
@@ -79,10 +82,22 @@ def test_hip_interaction_bit_exact_vs_oracle(B, F, D):
     td = torch.from_numpy(dense).cuda().requires_grad_()
     ts = torch.from_numpy(sparse).cuda().requires_grad_()
     arch = InteractionArch(F).cuda()
+    arch.pad_rows = pad_rows
     out = arch(td, ts)
+    width = D + (F + 1) * F // 2
+    assert tuple(out.shape) == (B, width)
+    if pad_rows and width % 4:
+        assert out.stride(0) == D + ((F + 1) * F // 2 + 3) // 4 * 4 and out.stride(1) == 1 and out.data_ptr() % 16 == 0
+        pad = torch.as_strided(out, (B, out.stride(0) - width), (out.stride(0), 1), out.storage_offset() + width)
+        assert float(pad.abs().max()) == 0.0  # pad columns are written as zeros
     np.testing.assert_array_equal(out.detach().cpu().numpy(), oracle.interaction_forward(dense, sparse))
     go = rng.standard_normal(tuple(out.shape)).astype(np.float32)
-    out.backward(torch.from_numpy(go).cuda())
+    g_dev = torch.from_numpy(go).cuda()
+    if pad_rows:  # the gradient as a row-padded view too (what the first over-arch layer hands back)
+        gbuf = torch.full((B, out.stride(0)), float("nan"), device="cuda")
+        gbuf[:, :width] = g_dev
+        g_dev = gbuf[:, :width]
+    out.backward(g_dev)
     gd, gs = oracle.interaction_backward(dense, sparse, go)
     np.testing.assert_array_equal(td.grad.cpu().numpy(), gd)
     np.testing.assert_array_equal(ts.grad.cpu().numpy(), gs)

@@ -28,12 +28,15 @@ def main():
         torch.cuda.synchronize()
         return s.elapsed_time(e) / n * 1e3
 
+    pad = os.environ.get("XIBENCH_PAD", "0") == "1"
+    if pad:
+        g = torch.randn(B, D + ((F + 1) * F // 2 + 3) // 4 * 4, device="cuda")[:, :D + (F + 1) * F // 2]
     with torch.no_grad():
-        f = t(lambda: _FusedDotInteraction.apply(dense, sparse))
-    out = _FusedDotInteraction.apply(dense, sparse)
-    fb = t(lambda: torch.autograd.grad(_FusedDotInteraction.apply(dense, sparse), (dense, sparse), g))
+        f = t(lambda: _FusedDotInteraction.apply(dense, sparse, pad))
+    out = _FusedDotInteraction.apply(dense, sparse, pad)
+    fb = t(lambda: torch.autograd.grad(_FusedDotInteraction.apply(dense, sparse, pad), (dense, sparse), g))
     rd, wr = B * (F + 1) * D * 4, B * (D + (F + 1) * F // 2) * 4
-    print(f"ablation={os.environ.get('TBE_INTERACTION_ABLATION', '0')}: forward {f:.1f} us ({(rd + wr) / f / 1e6:.2f} TB/s of "
+    print(f"pad_rows={pad} ablation={os.environ.get('TBE_INTERACTION_ABLATION', '0')}: forward {f:.1f} us ({(rd + wr) / f / 1e6:.2f} TB/s of "
           f"{(rd + wr) / 1e9:.2f} GB), forward+backward {fb:.1f} us")
 
 

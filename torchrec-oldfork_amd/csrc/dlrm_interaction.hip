@@ -75,15 +75,19 @@ struct XLoader {
 template <int D, int ABL = 0>  // ABL: ablation for tuning runs only (1 = no output stores, 2 = no MFMA)
 __global__ __launch_bounds__(256, (D <= 128 ? 4 : 2)) void interaction_fwd_kernel(const float* __restrict__ dense,
                                                                                   const float* __restrict__ sparse,
-                                                                                  float* __restrict__ out, int B, int F) {
+                                                                                  float* __restrict__ out, int B, int F,
+                                                                                  int64_t out_stride) {
   extern __shared__ float smem[];
   constexpr int NS = D / 16;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int R = F + 1;
   const int P = R * (R - 1) / 2;
-  const int OUT = D + P;
-  float* zs = smem + wave * ((P + 3) & ~3);
+  const int P4 = (P + 3) & ~3;
+  float* zs = smem + wave * P4;
+  // 16-B stores need 16-B aligned rows with room for the padded pair block (e.g. 480 floats for 128 + 351)
+  const bool vec_out = (out_stride & 3) == 0 && out_stride >= D + P4 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+  if (lane < P4 - P) zs[P + lane] = 0.f;  // the pad columns of a padded row read zeros, never garbage
   const int r16 = lane & 15;
   const int kq = lane >> 4;
   // rows >= R alias row R-1: their products only reach Z rows / columns >= R, which are never stored
@@ -145,19 +149,24 @@ __global__ __launch_bounds__(256, (D <= 128 ? 4 : 2)) void interaction_fwd_kerne
     // zs is private to the wave and LDS operations of a wave execute in order: a compiler barrier is
     // enough (a memory fence here would also wait for the global loads just issued)
     __builtin_amdgcn_wave_barrier();
-    float* orow = out + static_cast<int64_t>(b) * OUT;
+    float* orow = out + static_cast<int64_t>(b) * out_stride;
     if (ABL == 1) {  // keep the computation alive without writing the row
       if (zs[lane] == 1.2345e-31f) orow[0] = zs[lane];
       __builtin_amdgcn_wave_barrier();
       continue;
     }
-    if (lane < D / 4) {  // row stride OUT = D + P is not a multiple of 4 in general: scalar stores
-      orow[lane * 4 + 0] = dcur.x;
-      orow[lane * 4 + 1] = dcur.y;
-      orow[lane * 4 + 2] = dcur.z;
-      orow[lane * 4 + 3] = dcur.w;
+    if (vec_out) {  // padded rows (stride % 4 == 0): 16 B per lane, pad columns written as zeros
+      if (lane < D / 4) st4(orow + lane * 4, dcur);
+      for (int q = lane; q < P4 / 4; q += kWave) st4(orow + D + 4 * q, *reinterpret_cast<const float4*>(zs + 4 * q));
+    } else {  // the reference's dense [B, D + P] rows: D + P is not a multiple of 4 in general, scalar stores
+      if (lane < D / 4) {
+        orow[lane * 4 + 0] = dcur.x;
+        orow[lane * 4 + 1] = dcur.y;
+        orow[lane * 4 + 2] = dcur.z;
+        orow[lane * 4 + 3] = dcur.w;
+      }
+      for (int p = lane; p < P; p += kWave) orow[D + p] = zs[p];
     }
-    for (int p = lane; p < P; p += kWave) orow[D + p] = zs[p];
     __builtin_amdgcn_wave_barrier();  // zs is rewritten by the next sample
   }
 }
@@ -167,7 +176,8 @@ __global__ __launch_bounds__(256, 2) void interaction_bwd_kernel(const float* __
                                                                  const float* __restrict__ sparse,
                                                                  const float* __restrict__ grad_out,
                                                                  float* __restrict__ grad_dense,
-                                                                 float* __restrict__ grad_sparse, int B, int F) {
+                                                                 float* __restrict__ grad_sparse, int B, int F,
+                                                                 int64_t grad_stride) {
   extern __shared__ float smem[];
   constexpr int D = NT * 16;
   constexpr int XS = D + 16;  // B-operand reads (16k + 16n + c) % 32: conflict-free over a half-wave
@@ -217,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void interaction_bwd_kernel(const float* __
 #pragma unroll
     for (int t = 0; t < MAXP; ++t) {
       const int p = lane + t * kWave;
-      gpre[t] = p < P ? grad_out[static_cast<int64_t>(b) * OUT + D + p] : 0.f;
+      gpre[t] = p < P ? grad_out[static_cast<int64_t>(b) * grad_stride + D + p] : 0.f;
     }
   }
   for (; b < B; b += stride_b) {
@@ -234,13 +244,17 @@ __global__ __launch_bounds__(256, 2) void interaction_bwd_kernel(const float* __
         gs[j * GS + i] = gpre[t];
       }
     }
-    const float* grow = grad_out + static_cast<int64_t>(b) * OUT;
+    const float* grow = grad_out + static_cast<int64_t>(b) * grad_stride;
     float4 gdense = make_float4(0.f, 0.f, 0.f, 0.f);  // d(out)[:, :D] slice this lane adds to row 0
     if (lane < D / 4) {
-      gdense.x = grow[lane * 4 + 0];
-      gdense.y = grow[lane * 4 + 1];
-      gdense.z = grow[lane * 4 + 2];
-      gdense.w = grow[lane * 4 + 3];
+      if (((grad_stride & 3) | (reinterpret_cast<uintptr_t>(grad_out) & 15)) == 0) {
+        gdense = ld4(grow + lane * 4);
+      } else {
+        gdense.x = grow[lane * 4 + 0];
+        gdense.y = grow[lane * 4 + 1];
+        gdense.z = grow[lane * 4 + 2];
+        gdense.w = grow[lane * 4 + 3];
+      }
     }
     const int nb = b + stride_b;
     if (nb < B) {
@@ -252,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void interaction_bwd_kernel(const float* __
 #pragma unroll
       for (int t = 0; t < MAXP; ++t) {
         const int p = lane + t * kWave;
-        gpre[t] = p < P ? grad_out[static_cast<int64_t>(nb) * OUT + D + p] : 0.f;
+        gpre[t] = p < P ? grad_out[static_cast<int64_t>(nb) * grad_stride + D + p] : 0.f;
       }
     }
     wave_lds_fence();
@@ -323,8 +337,10 @@ static bool reserve_lds(K kernel, size_t bytes) {
 }
 
 extern "C" int tbe_dlrm_interaction_forward_f32(const float* dense, const float* sparse, int32_t B, int32_t F,
-                                                int32_t D, float* out, void* stream) {
+                                                int32_t D, float* out, int64_t out_row_stride, void* stream) {
   TBE_REQUIRE(B >= 0 && F >= 1 && F <= 31, "tbe_dlrm_interaction_forward_f32: F=%d outside [1, 31]", F);
+  TBE_REQUIRE(out_row_stride >= D + (F + 1) * F / 2, "tbe_dlrm_interaction_forward_f32: out_row_stride %lld < D + F(F+1)/2",
+              (long long)out_row_stride);
   TBE_REQUIRE(D == 16 || D == 32 || D == 64 || D == 128 || D == 256,
               "tbe_dlrm_interaction_forward_f32: D=%d not in {16,32,64,128,256}", D);
   if (B == 0) return TBE_OK;
@@ -342,16 +358,16 @@ extern "C" int tbe_dlrm_interaction_forward_f32(const float* dense, const float*
     return e ? atoi(e) : 0;
   }();
   if (ablation == 1 && D == 128) {
-    hipLaunchKernelGGL((interaction_fwd_kernel<128, 1>), grid, dim3(256), lds, st, dense, sparse, out, B, F);
+    hipLaunchKernelGGL((interaction_fwd_kernel<128, 1>), grid, dim3(256), lds, st, dense, sparse, out, B, F, out_row_stride);
     TBE_CHECK_LAUNCH("tbe_dlrm_interaction_forward_f32");
     return TBE_OK;
   }
   if (ablation == 2 && D == 128) {
-    hipLaunchKernelGGL((interaction_fwd_kernel<128, 2>), grid, dim3(256), lds, st, dense, sparse, out, B, F);
+    hipLaunchKernelGGL((interaction_fwd_kernel<128, 2>), grid, dim3(256), lds, st, dense, sparse, out, B, F, out_row_stride);
     TBE_CHECK_LAUNCH("tbe_dlrm_interaction_forward_f32");
     return TBE_OK;
   }
-#define TBE_IF(DD) hipLaunchKernelGGL(interaction_fwd_kernel<DD>, grid, dim3(256), lds, st, dense, sparse, out, B, F)
+#define TBE_IF(DD) hipLaunchKernelGGL(interaction_fwd_kernel<DD>, grid, dim3(256), lds, st, dense, sparse, out, B, F, out_row_stride)
   switch (D) {
     case 16: TBE_IF(16); break;
     case 32: TBE_IF(32); break;
@@ -365,9 +381,11 @@ extern "C" int tbe_dlrm_interaction_forward_f32(const float* dense, const float*
 }
 
 extern "C" int tbe_dlrm_interaction_backward_f32(const float* dense, const float* sparse, const float* grad_out,
-                                                 int32_t B, int32_t F, int32_t D, float* grad_dense,
-                                                 float* grad_sparse, void* stream) {
+                                                 int64_t grad_row_stride, int32_t B, int32_t F, int32_t D,
+                                                 float* grad_dense, float* grad_sparse, void* stream) {
   TBE_REQUIRE(B >= 0 && F >= 1 && F <= 27, "tbe_dlrm_interaction_backward_f32: F=%d outside [1, 27]", F);
+  TBE_REQUIRE(grad_row_stride >= D + (F + 1) * F / 2, "tbe_dlrm_interaction_backward_f32: grad_row_stride %lld < D + F(F+1)/2",
+              (long long)grad_row_stride);
   TBE_REQUIRE(D == 16 || D == 32 || D == 64 || D == 128, "tbe_dlrm_interaction_backward_f32: D=%d not in {16,32,64,128}", D);
   if (B == 0) return TBE_OK;
   TBE_REQUIRE(dense && sparse && grad_out && grad_dense && grad_sparse, "tbe_dlrm_interaction_backward_f32: null pointer");
@@ -387,7 +405,7 @@ extern "C" int tbe_dlrm_interaction_backward_f32(const float* dense, const float
     attr_set = true;
   }
 #define TBE_IB(NT) \
-  hipLaunchKernelGGL(interaction_bwd_kernel<NT>, grid, dim3(256), lds, st, dense, sparse, grad_out, grad_dense, grad_sparse, B, F)
+  hipLaunchKernelGGL(interaction_bwd_kernel<NT>, grid, dim3(256), lds, st, dense, sparse, grad_out, grad_dense, grad_sparse, B, F, grad_row_stride)
   switch (D) {
     case 16: TBE_IB(1); break;
     case 32: TBE_IB(2); break;

@@ -128,9 +128,9 @@ SIGNATURES = {
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_i32,
          c_i32, c_i32, c_float, c_void_p]),
     "tbe_dlrm_interaction_forward_f32": (
-        ctypes.c_int, [c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p, c_void_p]),
+        ctypes.c_int, [c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p, c_i64, c_void_p]),
     "tbe_dlrm_interaction_backward_f32": (
-        ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p]),
+        ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p]),
     "tbe_relu_backward_bias_grad_workspace_bytes": (c_size, [c_i64, c_i32]),
     "tbe_relu_backward_bias_grad_f32": (
         ctypes.c_int, [c_void_p, c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),

@@ -72,10 +72,14 @@ class DenseArch(nn.Module):
 
 class _FusedDotInteraction(torch.autograd.Function):
     """One HIP kernel each way (csrc/dlrm_interaction.hip, fp32 MFMA) instead of the reference's
-    cat + bmm + index + cat chain and its autograd backward (models/dlrm.py:206-219)."""
+    cat + bmm + index + cat chain and its autograd backward (models/dlrm.py:206-219).
+
+    `pad_rows`: the result [B, D + P] is a view of a [B, S] buffer with S = D + P rounded up to a multiple of 4 (479 ->
+    480 floats): rows start 16-B aligned, so the kernel stores 16 B per lane and the GEMMs of the next layer read aligned
+    rows (lda = S, K = D + P; tools/gemm_probe.py).  Values and shapes are those of the dense result."""
 
     @staticmethod
-    def forward(ctx, dense, sparse):
+    def forward(ctx, dense, sparse, pad_rows=False):
         from fbgemm_gpu import _lib
         from fbgemm_gpu._lib import check, ptr, stream_ptr
 
@@ -84,13 +88,15 @@ class _FusedDotInteraction(torch.autograd.Function):
         if dense.shape != (B, D) or sparse.device != dense.device:
             raise RuntimeError(f"dot interaction: dense {tuple(dense.shape)} does not match sparse {tuple(sparse.shape)} "
                                "(same batch, same embedding dim, same device required)")
-        out = torch.empty((B, D + (F + 1) * F // 2), dtype=torch.float32, device=dense.device)
+        width = D + (F + 1) * F // 2
+        stride = (D + ((F + 1) * F // 2 + 3) // 4 * 4) if pad_rows else width
+        buf = torch.empty((B, stride), dtype=torch.float32, device=dense.device)
         with torch.cuda.device(dense.device):
-            check(_lib.load().tbe_dlrm_interaction_forward_f32(ptr(dense), ptr(sparse), B, F, D, ptr(out),
+            check(_lib.load().tbe_dlrm_interaction_forward_f32(ptr(dense), ptr(sparse), B, F, D, ptr(buf), stride,
                                                                stream_ptr(dense.device)),
                   "tbe_dlrm_interaction_forward_f32")
         ctx.save_for_backward(dense, sparse)
-        return out
+        return buf if stride == width else buf[:, :width]
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -99,15 +105,17 @@ class _FusedDotInteraction(torch.autograd.Function):
 
         dense, sparse = ctx.saved_tensors
         B, F, D = sparse.shape
-        grad_out = grad_out.contiguous()
-        if grad_out.shape != (B, D + (F + 1) * F // 2):
+        width = D + (F + 1) * F // 2
+        if grad_out.shape != (B, width):
             raise RuntimeError(f"dot interaction backward: grad_out {tuple(grad_out.shape)} has the wrong shape")
+        if grad_out.dtype != torch.float32 or grad_out.stride(1) != 1 or grad_out.stride(0) < width:
+            grad_out = grad_out.float().contiguous()  # padded rows (stride >= width) are read in place
         gd, gs = torch.empty_like(dense), torch.empty_like(sparse)
         with torch.cuda.device(dense.device):
-            check(_lib.load().tbe_dlrm_interaction_backward_f32(ptr(dense), ptr(sparse), ptr(grad_out), B, F, D,
-                                                                ptr(gd), ptr(gs), stream_ptr(dense.device)),
+            check(_lib.load().tbe_dlrm_interaction_backward_f32(ptr(dense), ptr(sparse), ptr(grad_out), grad_out.stride(0),
+                                                                B, F, D, ptr(gd), ptr(gs), stream_ptr(dense.device)),
                   "tbe_dlrm_interaction_backward_f32")
-        return gd, gs
+        return gd, gs, None
 
 
 def _fused_interaction_ok(dense: torch.Tensor, sparse: torch.Tensor) -> bool:
@@ -123,13 +131,18 @@ class InteractionArch(nn.Module):
         super().__init__()
         self.F = num_sparse_features
         self.fused = True
+        # 16-B aligned output rows (a strided [B, D + P] view of a [B, 480] buffer at F = 26, D = 128); the first
+        # over-arch layer keeps the alignment for its input gradient (modules/mlp.py).  Off by default: measured on
+        # MI355X it buys nothing — the recorded GEMM choices run the 479-wide layer as fast at lda = 479 as at 480
+        # (0.481 / 0.464 / 0.439 ms vs 0.479 / 0.464 / 0.445 ms) and the interaction kernels are not store-bound.
+        self.pad_rows = os.environ.get("TORCHREC_AMD_PAD_INTERACTION", "0") == "1"
         self.register_buffer("triu_indices", torch.triu_indices(self.F + 1, self.F + 1, offset=1), persistent=False)
 
     def forward(self, dense_features: torch.Tensor, sparse_features: torch.Tensor) -> torch.Tensor:
         if self.F <= 0:
             return dense_features
         if self.fused and _fused_interaction_ok(dense_features, sparse_features):
-            return _FusedDotInteraction.apply(dense_features, sparse_features)
+            return _FusedDotInteraction.apply(dense_features, sparse_features, self.pad_rows)
         # generic shapes: the reference's formulation on torch ops
         combined = torch.cat((dense_features.unsqueeze(1), sparse_features), dim=1)
         interactions = torch.bmm(combined, combined.transpose(1, 2))

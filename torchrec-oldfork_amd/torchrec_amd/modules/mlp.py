@@ -42,7 +42,15 @@ class _LinearSplitKWgrad(torch.autograd.Function):
         else:
             x, weight = ctx.saved_tensors
             gy = gy.contiguous()
-        gx = gy @ weight if ctx.needs_input_grad[0] else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            if x.dim() == 2 and x.stride(1) == 1 and x.stride(0) > x.shape[1] and x.stride(0) % 4 == 0:
+                # the input is a row-padded view (16-B aligned rows, e.g. the 479-wide interaction output inside a 480-wide
+                # buffer): give its gradient the same layout, so that the consumer reads aligned rows too
+                gx = gy.new_empty((x.shape[0], x.stride(0)))[:, :x.shape[1]]
+                torch.mm(gy, weight, out=gx)
+            else:
+                gx = gy @ weight
         B = x.shape[0]
         c = ctx.chunks
         if c > 1 and B % c == 0:
