@@ -21,12 +21,20 @@ ROWS = [40, 7, 23, 90, 5]
 DIMS = [8, 8, 8, 8, 8]
 
 
+def _local(v):
+    """The rank's own tensor of a state value: a sharded table / state comes as a torch ShardedTensor when a process
+    group exists (as in the reference), everything else as a plain tensor."""
+    from torchrec_amd.distributed.embeddingbag import unwrap_local
+
+    return unwrap_local(v)
+
+
 def _clone(sd):
-    return copy.deepcopy({k: (v.detach().clone() if isinstance(v, torch.Tensor) else v) for k, v in sd.items()})
+    return {k: _local(v).detach().clone() for k, v in sd.items()}
 
 
 def _clone_opt(osd):
-    return {"state": {k: {kk: vv.detach().clone() for kk, vv in v.items()} for k, v in osd["state"].items()}}
+    return {"state": {k: {kk: _local(vv).detach().clone() for kk, vv in v.items()} for k, v in osd["state"].items()}}
 
 
 def _cpu_worker(rank, W, port, ret):
@@ -74,22 +82,30 @@ def _cpu_worker(rank, W, port, ret):
         fo = dmp.fused_optimizer
         for st in fo.state_dict()["state"].values():  # give the state non-trivial values
             for v in st.values():
-                v.copy_(torch.rand_like(v))
+                _local(v).copy_(torch.rand_like(_local(v)))
         saved, saved_opt = _clone(sd), _clone_opt(fo.state_dict())
         # perturb everything the checkpoint covers
         with torch.no_grad():
             for v in dmp.state_dict().values():
-                v.add_(1.0)
+                _local(v).add_(1.0)
             for st in fo.state_dict()["state"].values():
                 for v in st.values():
-                    v.mul_(3.0)
+                    _local(v).mul_(3.0)
         missing, unexpected = dmp.load_state_dict(saved)
         fo.load_state_dict(saved_opt)
         after, after_opt = dmp.state_dict(), fo.state_dict()
-        ok = (not missing and not unexpected and set(after) == set(saved) and all(torch.equal(after[k], saved[k]) for k in saved)
-              and all(torch.equal(after_opt["state"][k][kk], vv) for k, v in saved_opt["state"].items() for kk, vv in v.items()))
+        ok = (not missing and not unexpected and set(after) == set(saved) and all(torch.equal(_local(after[k]), saved[k]) for k in saved)
+              and all(torch.equal(_local(after_opt["state"][k][kk]), vv) for k, v in saved_opt["state"].items() for kk, vv in v.items()))
+        # loading the ShardedTensor objects themselves works too (what a reference-written checkpoint holds per rank)
+        dmp.load_state_dict(dmp.state_dict())
+        fo.load_state_dict(fo.state_dict())
+        from torch.distributed._shard.sharded_tensor import ShardedTensor
+        sharded_meta = {k: {"size": list(v.size()), "shards": [(list(m.shard_offsets), list(m.shard_sizes), m.placement.rank())
+                                                               for m in v.metadata().shards_metadata]}
+                        for k, v in after.items() if isinstance(v, ShardedTensor)}
+        opt_sharded = {kk: list(vv.size()) for v in after_opt["state"].values() for kk, vv in v.items() if isinstance(vv, ShardedTensor)}
         ret[rank] = {"ok": ok, "keys": sorted(saved.keys()), "kinds": kinds, "opt_keys": {k: sorted(v) for k, v in saved_opt["state"].items()},
-                     "shapes": {k: list(v.shape) for k, v in saved.items()}}
+                     "shapes": {k: list(v.shape) for k, v in saved.items()}, "sharded_meta": sharded_meta, "opt_sharded": opt_sharded}
     finally:
         dist.destroy_process_group()
 
@@ -113,6 +129,18 @@ def test_save_perturb_load_two_ranks_cpu():
         assert "head.weight" in got["keys"] and "head.bias" in got["keys"]
         fused = [t for t, k in kinds.items() if k != "data_parallel" and f"sparse.embedding_bags.{t}.weight" in got["keys"]]
         assert got["opt_keys"] == {f"sparse.embedding_bags.{t}.weight": [f"{t}.momentum1"] for t in fused}
+        # sharded tables (and their row-wise optimizer state) are ShardedTensors carrying the GLOBAL layout
+        # (embedding_kernel.py:63-122, batched_embedding_kernel.py:166-246); replicated tables are plain tensors
+        for t in fused:
+            m = got["sharded_meta"][f"sparse.embedding_bags.{t}.weight"]
+            rows = ROWS[int(t[1:])]
+            assert m["size"] == [rows, 8]
+            if kinds[t] == "row_wise":
+                assert m["shards"] == [([0, 0], [(rows + 1) // 2, 8], 0), ([(rows + 1) // 2, 0], [rows - (rows + 1) // 2, 8], 1)]
+            else:
+                assert len(m["shards"]) == 1 and m["shards"][0][:2] == ([0, 0], [rows, 8]) and m["shards"][0][2] == r
+            assert got["opt_sharded"][f"{t}.momentum1"] == [rows]
+        assert not any(f".{t}." in k for k in got["sharded_meta"] for t, kk in kinds.items() if kk == "data_parallel")
 
 
 @pytest.mark.gpu
@@ -145,7 +173,7 @@ def test_save_perturb_load_with_row_cache_gpu():
     for _ in range(3):
         step()
     fo = sebc.fused_optimizer
-    saved, saved_opt = _clone(sebc.state_dict()), _clone_opt(fo.state_dict())
+    saved, saved_opt = _clone(sebc.state_dict()), _clone_opt(fo.state_dict())  # no process group: plain tensors
     assert sorted(saved) == ["embedding_bags.t0.weight", "embedding_bags.t1.weight", "embedding_bags.t2.weight"]
     assert {k: sorted(v) for k, v in saved_opt["state"].items()} == {f"embedding_bags.t{i}.weight": [f"t{i}.momentum1"] for i in range(3)}
     assert float(saved_opt["state"]["embedding_bags.t0.weight"]["t0.momentum1"].abs().sum()) > 0  # read through the cache write-back

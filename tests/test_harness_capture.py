@@ -106,15 +106,21 @@ def _mine_worker(rank, W, port, ret):
             outs.append({k: v.detach().numpy().copy() for k, v in out.to_dict().items()})
             lpk = dict(zip(out.keys(), out.length_per_key()))
         sd_keys = sorted(dmp.state_dict().keys())
-        shards = {k: v.numpy().copy() for k, v in dmp.state_dict().items()}
+        from torchrec_amd.distributed.embeddingbag import unwrap_local
+
+        shards = {k: unwrap_local(v).numpy().copy() for k, v in dmp.state_dict().items()}
+        from torch.distributed._shard.sharded_tensor import ShardedTensor
+
+        st_meta = {k: [[list(m.shard_offsets), list(m.shard_sizes), str(m.placement)] for m in v.metadata().shards_metadata]
+                   for k, v in dmp.state_dict().items() if isinstance(v, ShardedTensor)}
         fo = dmp.fused_optimizer
         ada = build({"learning_rate": 0.1, "optimizer": EmbOptimType.EXACT_ROWWISE_ADAGRAD, "eps": 1e-3}).fused_optimizer
         ret[rank] = {
-            "outs": outs, "lpk": lpk, "sd_keys": sd_keys, "shards": shards, "named_parameters": [n for n, _ in dmp.named_parameters()],
+            "outs": outs, "lpk": lpk, "sd_keys": sd_keys, "shards": shards, "st_meta": st_meta, "named_parameters": [n for n, _ in dmp.named_parameters()],
             "fo_params": sorted(fo.params.keys()), "fo_sd_keys": sorted(fo.state_dict().keys()),
             "fo_state_sgd": {k: sorted(v.keys()) for k, v in fo.state_dict()["state"].items()},
             "fo_state_ada": {k: sorted(v.keys()) for k, v in ada.state_dict()["state"].items()},
-            "fo_shapes_ada": {k: {kk: [list(vv.shape)] for kk, vv in v.items()} for k, v in ada.state_dict()["state"].items()},
+            "fo_shapes_ada": {k: {kk: [list(unwrap_local(vv).shape)] for kk, vv in v.items()} for k, v in ada.state_dict()["state"].items()},
         }
     finally:
         dist.destroy_process_group()
@@ -150,6 +156,10 @@ def test_sharded_collection_matches_reference_capture(W):
             w = mine["shards"][f"ebc.embedding_bags.{name}.weight"]
             assert list(w.shape) == s["sizes"]  # the reference planner's shard sizes (enumerators.py:277-312)
             np.testing.assert_array_equal(w, arr0[f"global_weight{int(name[1:])}"][r0:r0 + rows])
+        # the state values are ShardedTensors whose GLOBAL shard lists equal the reference plan's (offsets, sizes, placement)
+        for name in shard_of:
+            got = mine["st_meta"][f"ebc.embedding_bags.{name}.weight"]
+            assert got == [[s_["offsets"], s_["sizes"], s_["placement"]] for s_ in meta["plan"][name]["shards"]]
         # ---- fused optimizer surface ----------------------------------------------------------------------------------
         assert mine["fo_params"] == sorted(meta["fused_optimizer_param_keys"])
         assert mine["fo_sd_keys"] == meta["fused_optimizer_state_dict_keys"] == ["state"]

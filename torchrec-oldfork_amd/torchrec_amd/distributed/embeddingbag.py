@@ -87,6 +87,41 @@ def _default_tbe_factory(specs, ftm, pooling_mode, device, fused_params):
         feature_table_map=ftm, pooling_mode=pooling_mode, device=device, **fused_params)
 
 
+def _placement(rank: int, me: int, device: torch.device) -> str:
+    """`rank:R/device` placement string of a shard (torch.distributed._shard): this rank's shards sit on its own device,
+    a peer's on the device with the peer's index (one process per GPU of one node)."""
+    if device.type != "cuda":
+        return f"rank:{rank}/cpu"
+    return f"rank:{rank}/cuda:{device.index if rank == me else rank}"
+
+
+def wrap_sharded(local: Optional[torch.Tensor], global_size: List[int], shards: List[Tuple[List[int], List[int], int]], pg,
+                 me: int, device: torch.device):
+    """A torch ShardedTensor over this rank's `local` shard (None if it holds none) of a tensor of `global_size` cut into
+    `shards` = [(offsets, sizes, rank), ...] — what the reference puts into state_dict() and the fused optimizer state for
+    every sharded table when a process group exists (embedding_kernel.py:63-122, batched_embedding_kernel.py:166-246)."""
+    from torch.distributed._shard.metadata import ShardMetadata as TorchShardMetadata
+    from torch.distributed._shard.sharded_tensor import Shard, ShardedTensor, ShardedTensorMetadata, TensorProperties
+
+    metas = [TorchShardMetadata(shard_offsets=list(o), shard_sizes=list(z), placement=_placement(r, me, device))
+             for o, z, r in shards]
+    mine = [Shard(local, m) for m, (_, _, r) in zip(metas, shards) if r == me and local is not None]
+    dtype = local.dtype if local is not None else torch.float32
+    meta = ShardedTensorMetadata(shards_metadata=metas, size=torch.Size(global_size),
+                                 tensor_properties=TensorProperties(dtype=dtype, requires_grad=False))
+    return ShardedTensor._init_from_local_shards_and_global_metadata(mine, meta, process_group=pg)
+
+
+def unwrap_local(value):
+    """A tensor out of a state_dict value: the local shard of a ShardedTensor, the tensor itself otherwise."""
+    if hasattr(value, "local_shards") and hasattr(value, "metadata"):
+        shards = value.local_shards()
+        if len(shards) != 1:
+            raise ValueError(f"expected exactly one local shard, found {len(shards)}")
+        return shards[0].tensor
+    return value
+
+
 class _LocalTable:
     def __init__(self, cfg: EmbeddingBagConfig, local_rows: int, row_offset: int, row_wise: bool,
                  compute_kernel: str = "batched_fused") -> None:
@@ -213,7 +248,8 @@ class EmbeddingFusedOptimizer:
     nested under the parameter key (:241-249).  Tensors are views of the module's storage; for MANAGED_CACHING
     tables the HBM row cache is written back before they are handed out."""
 
-    def __init__(self, emb_module, table_names: List[str], key_prefix: str = "") -> None:
+    def __init__(self, emb_module, table_names: List[str], key_prefix: str = "", wrap=None) -> None:
+        self._wrap = wrap  # (table name, local tensor) -> ShardedTensor | tensor; None = plain tensors
         self._emb_module = emb_module
         self._table_names = list(table_names)
         self._key_prefix = key_prefix
@@ -254,7 +290,9 @@ class EmbeddingFusedOptimizer:
         self._save_param_groups = save
 
     def state_dict(self) -> Dict[str, Any]:
-        out: Dict[str, Any] = {"state": {k: dict(v) for k, v in self.state.items()}}
+        w = self._wrap
+        out: Dict[str, Any] = {"state": {k: {kk: (w(kk.rsplit(".", 1)[0], vv) if w is not None else vv) for kk, vv in v.items()}
+                                         for k, v in self.state.items()}}
         if self._save_param_groups:
             out["param_groups"] = [{"params": sorted(self._params.keys()), "lr": self.param_groups[0]["lr"]}]
         return out
@@ -269,7 +307,7 @@ class EmbeddingFusedOptimizer:
                 if set(st.keys()) != set(mine[k].keys()):
                     raise ValueError(f"fused optimizer state of {k}: {sorted(mine[k].keys())} vs {sorted(st.keys())}")
                 for name, t in st.items():
-                    mine[k][name].copy_(t)
+                    mine[k][name].copy_(unwrap_local(t))
         if "param_groups" in state_dict and state_dict["param_groups"]:
             self.param_groups[0]["lr"] = state_dict["param_groups"][0].get("lr", self.param_groups[0]["lr"])
             self._emb_module.set_learning_rate(self.param_groups[0]["lr"])
@@ -358,6 +396,9 @@ class ShardedEmbeddingBagCollection(nn.Module):
         self._slab_stride = torch.tensor(self._D_local_per_rank, dtype=torch.int32, device=dev)
         self._vec_ok = all(d % 4 == 0 for d in g_dim)
         self._layout_cache: Dict[int, Dict[str, Any]] = {}
+        # state_dict() / fused-optimizer state as torch ShardedTensors whenever a process group exists (the reference's
+        # behaviour); False hands out the plain local shards
+        self.sharded_tensor_state = True
         self._kjt_cache: Dict[Tuple, Any] = {}
         self._output_buffer: Optional[torch.Tensor] = None  # see set_output_buffer
         # ---- local tables + TBE ----------------------------------------------------------------
@@ -397,7 +438,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
                 self._emb_module.set_feature_pooling(local_pooling * W)
             self._init_parameters()
             self._optim = EmbeddingFusedOptimizer(self._emb_module, [lt.cfg.name for lt in self._local_tables],
-                                                  key_prefix="embedding_bags.")
+                                                  key_prefix="embedding_bags.", wrap=self._wrap)
         else:
             self._optim = None
         # global-column addressing of the sharded features for the world_size == 1 "write into one buffer" path
@@ -467,13 +508,35 @@ class ShardedEmbeddingBagCollection(nn.Module):
         return {lt.cfg.name: (w, lt.row_offset)
                 for lt, w in zip(self._local_tables, self._emb_module.split_embedding_weights())}
 
+    def _table_shards(self, name: str, cols: Optional[int] = None) -> Tuple[List[int], List[Tuple[List[int], List[int], int]]]:
+        """(global size, [(offsets, sizes, rank)]) of a sharded table's weight (cols = D) or row-wise state (cols None)."""
+        t = next(i for i, c in enumerate(self._embedding_bag_configs) if c.name == name)
+        cfg, kind, W = self._embedding_bag_configs[t], self._table_kind[t], self._world_size
+        if kind == -1:
+            rows, off, out = rw_shard_rows(cfg.num_embeddings, W), 0, []
+            for r in range(W):
+                out.append(([off, 0], [rows[r], cols], r) if cols is not None else ([off], [rows[r]], r))
+                off += rows[r]
+        else:
+            out = [([0, 0], [cfg.num_embeddings, cols], kind) if cols is not None else ([0], [cfg.num_embeddings], kind)]
+        return ([cfg.num_embeddings, cols] if cols is not None else [cfg.num_embeddings]), out
+
+    def _wrap(self, name: str, local: torch.Tensor):
+        if not self.sharded_tensor_state or self._pg is None:
+            return local
+        size, shards = self._table_shards(name, local.shape[1] if local.dim() == 2 else None)
+        if local.dim() == 2 and local.shape[1] != size[1]:
+            return local
+        return wrap_sharded(local, size, shards, self._pg, self._rank, self._device)
+
     def state_dict(self, destination=None, prefix: str = "", keep_vars: bool = False):
         """`embedding_bags.<table>.weight` for EVERY table this rank holds (embeddingbag.py:405-416): the local
         shard [rows_local, D] of a sharded table, the whole [rows, D] of a replicated one.  The tensors alias
         the modules' storage (host views, cache written back, for MANAGED_CACHING tables)."""
         destination = {} if destination is None else destination
         for name, (w, _) in self.local_shards().items():
-            destination[f"{prefix}embedding_bags.{name}.weight"] = w if keep_vars else w.detach()
+            # with a process group the value is a ShardedTensor over the shard, as the reference's (sharded_tensor_state)
+            destination[f"{prefix}embedding_bags.{name}.weight"] = self._wrap(name, w if keep_vars else w.detach())
         for name, w in self.dp_tables().items():
             destination[f"{prefix}embedding_bags.{name}.weight"] = w if keep_vars else w.detach()
         return destination
@@ -490,7 +553,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
                 if strict:
                     missing_keys.append(key)
                 continue
-            src = state_dict[key]
+            src = unwrap_local(state_dict[key])
             if tuple(src.shape) == tuple(w.shape):
                 pass
             elif src.dim() == 2 and src.shape[0] == cfg[name].num_embeddings and src.shape[1] == w.shape[1]:
