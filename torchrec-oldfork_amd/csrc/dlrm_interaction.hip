@@ -40,6 +40,11 @@ __device__ __forceinline__ void wave_lds_fence() {
 #endif
 }
 
+__device__ __forceinline__ float4 ldnt4(const float* p) {  // streaming (non-temporal) 16-B load
+  const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+
 // index of pair (i, j), i < j < R, in torch.triu_indices(R, R, offset=1) row-major order
 __device__ __forceinline__ int triu_index(int i, int j, int R) { return i * (2 * R - i - 1) / 2 + (j - i - 1); }
 
@@ -102,10 +107,10 @@ __global__ __launch_bounds__(256, (D <= 128 ? 4 : 2)) void interaction_fwd_kerne
                                  : sparse + (static_cast<int64_t>(b) * F + (row0 - 1)) * D) + 4 * kq;
     const float* x1 = sparse + (static_cast<int64_t>(b) * F + (row1 - 1)) * D + 4 * kq;  // row1 >= 1 when R >= 2
 #pragma unroll
-    for (int s = 0; s < NS; ++s) xa[s] = ld4(x0 + 16 * s);
+    for (int s = 0; s < NS; ++s) xa[s] = (ABL >= 3) ? ldnt4(x0 + 16 * s) : ld4(x0 + 16 * s);
     if (R > 16) {
 #pragma unroll
-      for (int s = 0; s < NS; ++s) xb[s] = ld4(x1 + 16 * s);
+      for (int s = 0; s < NS; ++s) xb[s] = (ABL >= 3) ? ldnt4(x1 + 16 * s) : ld4(x1 + 16 * s);
     } else {
 #pragma unroll
       for (int s = 0; s < NS; ++s) xb[s] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -135,7 +140,20 @@ __global__ __launch_bounds__(256, (D <= 128 ? 4 : 2)) void interaction_fwd_kerne
     // The operand registers are dead from here on: the NEXT sample's loads go out now and fly while this
     // sample's products are re-staged and stored (ablation: the store phase cost 63 of 285 us when it ran
     // after the loads had been waited for).
-    const float4 dcur = dpass;
+    // out[:, :D] = dense[b] goes out BEFORE the next sample's loads are issued: `dpass` is then reloaded in place.  (Kept
+    // live across the loads, the compiler parks the new value in a second register and copies it at the loop latch
+    // behind an `s_waitcnt vmcnt(0)` — a full stop for every load AND store of the iteration.)
+    float* orow = out + static_cast<int64_t>(b) * out_stride;
+    if (ABL != 1 && lane < D / 4) {
+      if (vec_out) {
+        st4(orow + lane * 4, dpass);
+      } else {  // rows of D + P floats are not 16-B aligned in general: scalar stores
+        orow[lane * 4 + 0] = dpass.x;
+        orow[lane * 4 + 1] = dpass.y;
+        orow[lane * 4 + 2] = dpass.z;
+        orow[lane * 4 + 3] = dpass.w;
+      }
+    }
     if (b + stride_b < B) issue_loads(b + stride_b);
     // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
 #pragma unroll
@@ -149,23 +167,31 @@ __global__ __launch_bounds__(256, (D <= 128 ? 4 : 2)) void interaction_fwd_kerne
     // zs is private to the wave and LDS operations of a wave execute in order: a compiler barrier is
     // enough (a memory fence here would also wait for the global loads just issued)
     __builtin_amdgcn_wave_barrier();
-    float* orow = out + static_cast<int64_t>(b) * out_stride;
     if (ABL == 1) {  // keep the computation alive without writing the row
       if (zs[lane] == 1.2345e-31f) orow[0] = zs[lane];
       __builtin_amdgcn_wave_barrier();
       continue;
     }
+    // Straight-line stores (fixed trip counts, predicated): inside a loop with a run-time trip count the compiler puts a
+    // full `s_waitcnt vmcnt(0)` in front of the stores, i.e. the wave would sit out the whole latency of the next
+    // sample's loads it has just issued before it stores this sample (seen in the ISA; cost ~60 of 270 us).
+    constexpr int MAXT = 8;   // pairs: P <= 31 * 32 / 2 = 496 <= 8 * 64
+    constexpr int MAXQ = 2;   // float4 groups of the padded pair block: <= 124 <= 2 * 64
     if (vec_out) {  // padded rows (stride % 4 == 0): 16 B per lane, pad columns written as zeros
-      if (lane < D / 4) st4(orow + lane * 4, dcur);
-      for (int q = lane; q < P4 / 4; q += kWave) st4(orow + D + 4 * q, *reinterpret_cast<const float4*>(zs + 4 * q));
-    } else {  // the reference's dense [B, D + P] rows: D + P is not a multiple of 4 in general, scalar stores
-      if (lane < D / 4) {
-        orow[lane * 4 + 0] = dcur.x;
-        orow[lane * 4 + 1] = dcur.y;
-        orow[lane * 4 + 2] = dcur.z;
-        orow[lane * 4 + 3] = dcur.w;
+#pragma unroll
+      for (int t = 0; t < MAXQ; ++t) {
+        const int q = lane + t * kWave;
+        if (q < P4 / 4) st4(orow + D + 4 * q, *reinterpret_cast<const float4*>(zs + 4 * q));
       }
-      for (int p = lane; p < P; p += kWave) orow[D + p] = zs[p];
+    } else {  // the reference's dense [B, D + P] rows: scalar stores
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t) {
+        const int p = lane + t * kWave;
+        if (p < P) {
+          if (ABL == 4) __builtin_nontemporal_store(zs[p], orow + D + p);
+          else orow[D + p] = zs[p];
+        }
+      }
     }
     __builtin_amdgcn_wave_barrier();  // zs is rewritten by the next sample
   }
@@ -359,6 +385,14 @@ extern "C" int tbe_dlrm_interaction_forward_f32(const float* dense, const float*
   }();
   if (ablation == 1 && D == 128) {
     hipLaunchKernelGGL((interaction_fwd_kernel<128, 1>), grid, dim3(256), lds, st, dense, sparse, out, B, F, out_row_stride);
+    TBE_CHECK_LAUNCH("tbe_dlrm_interaction_forward_f32");
+    return TBE_OK;
+  }
+  if ((ablation == 3 || ablation == 4) && D == 128) {
+    if (ablation == 3)
+      hipLaunchKernelGGL((interaction_fwd_kernel<128, 3>), grid, dim3(256), lds, st, dense, sparse, out, B, F, out_row_stride);
+    else
+      hipLaunchKernelGGL((interaction_fwd_kernel<128, 4>), grid, dim3(256), lds, st, dense, sparse, out, B, F, out_row_stride);
     TBE_CHECK_LAUNCH("tbe_dlrm_interaction_forward_f32");
     return TBE_OK;
   }

@@ -130,12 +130,26 @@ class GraphedSegment(nn.Module):
                 n_in = sum(1 for x in self.static_inputs if x.requires_grad)
                 if len(param_grad_sinks) != len(self._params):
                     raise ValueError("one gradient sink per parameter")
-                for g, sink in zip(grads[n_in:], param_grad_sinks):
-                    if g is None:
-                        sink.zero_()
-                    else:
-                        torch.mul(g, sink_scale, out=sink)
-                self.param_grad_sinks = list(param_grad_sinks)
+                pg_ = list(grads[n_in:])
+                sinks = list(param_grad_sinks)
+                consecutive = all(s_.is_contiguous() for s_ in sinks) and all(
+                    sinks[i + 1].data_ptr() == sinks[i].data_ptr() + sinks[i].numel() * sinks[i].element_size()
+                    for i in range(len(sinks) - 1))
+                if consecutive and sinks and all(g is not None for g in pg_):
+                    # the sinks are consecutive slices of ONE flat buffer: one batched copy + one scale instead of
+                    # a kernel per parameter (16 launches of ~5 us per step at the 8-GPU per-rank batch)
+                    total = sum(s_.numel() for s_ in sinks)
+                    flat_slice = torch.as_strided(sinks[0], (total,), (1,), sinks[0].storage_offset())
+                    torch.cat([g.reshape(-1) for g in pg_], out=flat_slice)
+                    if sink_scale != 1.0:
+                        flat_slice.mul_(sink_scale)
+                else:
+                    for g, sink in zip(pg_, sinks):
+                        if g is None:
+                            sink.zero_()
+                        else:
+                            torch.mul(g, sink_scale, out=sink)
+                self.param_grad_sinks = sinks
         it = iter(grads)
         self.static_grad_inputs = [next(it) if x.requires_grad else None for x in self.static_inputs]
         self.static_grad_inputs += list(it)  # parameter gradients, in self._params order
