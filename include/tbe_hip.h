@@ -206,6 +206,9 @@ int tbe_debug_sort_timeouts(int64_t* count);
 /* Development aid: device buffer of int64 [7 passes][256 segments][8] that tbe_sort_pairs' pass kernels fill
  * with 100 MHz wall-clock stamps per phase (NULL switches it off; tools/sstamps.py). */
 int tbe_debug_set_sort_stamps(void* device_buffer);
+/* Development aid of the same kind for the interaction forward (TBE_INTERACTION_ABLATION=6): 8 workgroups x 4 waves x
+ * 32 samples x 6 cycle-counter stamps (uint64), NULL switches it off. */
+int tbe_debug_set_interaction_stamps(void* device_buffer);
 int tbe_backward_apply_f32(const uint64_t* feat_weights, const int32_t* feat_D,
                            const int64_t* feat_out_offset, const int64_t* feat_rows,
                            const int64_t* feat_row_base, const uint64_t* feat_state0,
@@ -413,6 +416,13 @@ int tbe_dense_to_jagged_2d_f32(const float* dense, const int64_t* offsets, int32
  * out[i] = i - offsets[bag(i)] for i in [0, range_size). offsets has n entries (no total). */
 int tbe_offsets_range(const int64_t* offsets, int64_t n, int64_t range_size, int64_t* out,
                       void* stream);
+
+/* dst[y, :] = src[rows[y], :] for y in [0, n_rows): rows of `row_bytes` bytes (a multiple of 16, 16-byte aligned bases).
+ * The send-order gather of the input exchange when every feature has the same number of ids per batch (the
+ * reference permutes the whole KJT: torchrec/distributed/dist_data.py:257-263); `rows` is a device int32 array whose
+ * entries the caller guarantees are < src_rows (not checked on the device). */
+int tbe_copy_rows(const void* src, int64_t src_rows, const int32_t* rows, int32_t n_rows,
+                  int64_t row_bytes, void* dst, void* stream);
 
 #ifdef __cplusplus
 }

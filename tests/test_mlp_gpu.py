@@ -108,3 +108,37 @@ def test_weighted_colsum_and_one_output_linear(B, N):
     torch.testing.assert_close(xi.grad, xr.grad, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(lin.weight.grad, ref_lin.weight.grad, rtol=1e-4, atol=1e-3)
     torch.testing.assert_close(lin.bias.grad, ref_lin.bias.grad, rtol=1e-4, atol=1e-3)
+
+
+def test_wgrad_on_side_stream_matches_inline():
+    """modules/mlp.py _WgradOverlap: weight gradients computed on the side stream and accumulated out of band are
+    bit-identical to the ones autograd accumulates (same kernels, same order), also when a gradient already exists."""
+    from torchrec_amd.modules.mlp import MLP, _WgradOverlap
+
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(3)
+    mlp = MLP(96, [256, 128, 64], device=dev)
+    x = torch.randn(8192, 96, device=dev, requires_grad=True)
+    g = torch.randn(8192, 64, device=dev)
+
+    def run(overlap, passes):
+        for p in mlp.parameters():
+            p.grad = None
+        x.grad = None
+        for _ in range(passes):
+            if overlap:
+                _WgradOverlap.enable(dev)
+            try:
+                mlp(x).backward(g)
+            finally:
+                if overlap:
+                    _WgradOverlap.disable()  # joins
+        torch.cuda.synchronize()
+        return [p.grad.clone() for p in mlp.parameters()] + [x.grad.clone()]
+
+    for passes in (1, 2):
+        want = run(False, passes)
+        got = run(True, passes)
+        assert not _WgradOverlap.on and not _WgradOverlap.pending
+        for a, b in zip(want, got):
+            assert torch.equal(a, b)

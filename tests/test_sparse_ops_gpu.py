@@ -166,3 +166,28 @@ def test_full_size_index_op_properties():
     noffs = torch.ops.fbgemm.asynchronous_complete_cumsum(nl)
     bucket_of_dst = torch.bucketize(torch.arange(N, device="cuda"), noffs[:: F * B][1:].contiguous(), right=True)
     assert torch.equal(bucket_of_dst[unb], ids // blocks[feat_of])  # each id landed in its bucket's segment
+
+
+@pytest.mark.parametrize("dtype", [torch.int64, torch.float32, torch.int32])
+@pytest.mark.parametrize("rows,cols", [(26, 8192), (26, 8192 * 3), (5, 4), (1, 65536), (40, 1028), (300, 36)])
+def test_copy_rows_is_index_select(dtype, rows, cols):
+    """torch.ops.tbe_hip.copy_rows (send-order gather of the input exchange): bit-exact row gather, repeated and
+    out-of-order rows included."""
+    from torchrec_amd.distributed import _device_ops  # noqa: F401
+
+    g = torch.Generator(device="cuda")
+    g.manual_seed(rows * cols)
+    src = torch.randint(-(1 << 30), 1 << 30, (rows, cols), generator=g, device="cuda").to(dtype)
+    for order in (list(reversed(range(rows))), [0] * 3, list(range(0, rows, 2)) + list(range(1, rows, 2)), []):
+        idx = torch.tensor(order, dtype=torch.int32, device="cuda")
+        out = torch.ops.tbe_hip.copy_rows(src, idx)
+        assert out.shape == (len(order), cols)
+        assert torch.equal(out, src[idx.long()])
+
+
+def test_copy_rows_rejects_unaligned_rows():
+    from torchrec_amd.distributed import _device_ops  # noqa: F401
+
+    src = torch.zeros((4, 3), dtype=torch.int32, device="cuda")
+    with pytest.raises(RuntimeError, match="16"):
+        torch.ops.tbe_hip.copy_rows(src, torch.tensor([1, 0], dtype=torch.int32, device="cuda"))

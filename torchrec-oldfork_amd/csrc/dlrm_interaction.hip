@@ -197,6 +197,217 @@ __global__ __launch_bounds__(256, (D <= 128 ? 4 : 2)) void interaction_fwd_kerne
   }
 }
 
+// A 4-byte global store the compiler cannot merge, split or skip: the LDS-DMA kernel below counts its stores to
+// wait for exactly the copies in front of them (s_waitcnt vmcnt(N) retires vector-memory operations in issue order).
+__device__ __forceinline__ void vm_store_dword(float* p, float v) {
+  asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void vm_wait_all_but() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Waits until at most `n` of this wave's vector-memory operations are outstanding (n <= 12, wave-uniform).
+__device__ __forceinline__ void vm_wait_all_but(int n) {
+  switch (n) {
+    case 1: vm_wait_all_but<1>(); break;
+    case 2: vm_wait_all_but<2>(); break;
+    case 3: vm_wait_all_but<3>(); break;
+    case 4: vm_wait_all_but<4>(); break;
+    case 5: vm_wait_all_but<5>(); break;
+    case 6: vm_wait_all_but<6>(); break;
+    case 7: vm_wait_all_but<7>(); break;
+    case 8: vm_wait_all_but<8>(); break;
+    case 9: vm_wait_all_but<9>(); break;
+    case 10: vm_wait_all_but<10>(); break;
+    case 11: vm_wait_all_but<11>(); break;
+    case 12: vm_wait_all_but<12>(); break;
+    default: vm_wait_all_but<0>(); break;
+  }
+}
+
+// Forward, LDS-DMA form (D >= 64).  The register form above fetches MFMA-fragment-shaped pieces: one load instruction
+// touches 16 rows x 64 B, i.e. 16 half-used 128-B lines, and the texture-address path — not HBM — bounds it (loads alone
+// 4.5 TB/s).  Here a sample's rows are copied global -> LDS as whole lines by `global_load_lds_dwordx4` (64 lanes x 16 B
+// = 1 KiB contiguous per instruction, no VGPR in between), and the fragments are read from LDS with ds_read_b128.
+//   * The LDS image of an instruction is lane-linear (destination = wave-uniform base + 16 * lane), so the bank
+//     swizzle goes on the SOURCE address: slot `pp` of row r holds the 16-B piece pp ^ (r & 15) of that row.  A reader
+//     of piece p of row r looks at slot p ^ (r & 15): the 16 rows one ds_read_b128 lane group covers land on 16
+//     different 16-B bank slots.  Within a row the lanes still cover whole 128-B lines (the XOR permutes pieces inside
+//     aligned groups).
+//   * Column order of the contraction is the register form's, (segment s, element e, quarter q): bit-identical output.
+//   * One LDS image per wave: once the fragments are in registers the image is dead, so the NEXT sample's copy is
+//     issued before the MFMAs and flies during the products, the re-staging and the stores.
+//   * The wait for that copy must not include the stores issued after it (a store retires only when L2 has taken it:
+//     microseconds under load, per sample and per wave).  The dense [B, D + P] layout therefore stores through
+//     vm_store_dword — a fixed number of store instructions per sample, every lane active (lanes past the end repeat
+//     the last element) — and waits with vmcnt(that number).
+// development aid (tbe_debug_set_interaction_stamps + TBE_INTERACTION_ABLATION=6): the waves of the first 8 workgroups
+// write 6 cycle-counter stamps per sample for their first 32 samples
+static uint64_t* g_interaction_stamps = nullptr;
+constexpr int kStampBlocks = 8, kStampIters = 32, kStampsPerIter = 6;
+
+template <int D, int ABL = 0>  // ABL (tuning runs): 1 = no output stores, 2 = no MFMA, 5 = copies only, 6 = stamps
+__global__ __launch_bounds__(256, 2) void interaction_fwd_glds_kernel(const float* __restrict__ dense,
+                                                                     const float* __restrict__ sparse,
+                                                                     float* __restrict__ out, int B, int F,
+                                                                     int64_t out_stride, uint64_t* stamps) {
+  extern __shared__ float smem[];
+  constexpr int NS = D / 16;
+  constexpr int PR = D / 4;          // 16-B pieces per row
+  constexpr int RPI = kWave / PR;    // rows per copy instruction
+  constexpr int MAXI = 32 / RPI;     // copy instructions for 32 rows
+  static_assert(PR >= 16 && PR <= kWave, "LDS-DMA form needs 64 <= D <= 256");
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int R = F + 1;
+  const int P = R * (R - 1) / 2;
+  const int P4 = (P + 3) & ~3;
+  const int NI = (R + RPI - 1) / RPI;
+  float* xs = smem + wave * (NI * RPI * D + P4);
+  float* zs = xs + NI * RPI * D;
+  const bool vec_out = (out_stride & 3) == 0 && out_stride >= D + P4 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+  if (lane < P4 - P) zs[P + lane] = 0.f;
+  const int r16 = lane & 15;
+  const int kq = lane >> 4;
+  const int row0 = min(r16, R - 1);       // rows >= R alias row R-1 (their products are never stored)
+  const int row1 = min(16 + r16, R - 1);
+  const int stride_b = gridDim.x * 4;
+  // this lane's source of copy instruction i: row min(i * RPI + lane / PR, R - 1), piece (lane % PR) ^ (row & 15)
+  int src_off[MAXI];  // float offset inside the sample's sparse block; row 0 (the dense row) only occurs at i = 0
+#pragma unroll
+  for (int i = 0; i < MAXI; ++i) {
+    const int row = min(i * RPI + lane / PR, R - 1);
+    const int piece = (lane % PR) ^ (row & 15);
+    src_off[i] = (row - 1) * D + 4 * piece;
+  }
+  const bool dense_lane = lane < PR;  // instruction 0 fetches row 0 with its first PR lanes
+  auto issue_copy = [&](int b) {
+    const float* sp = sparse + static_cast<int64_t>(b) * F * D;
+    const float* dn = dense + static_cast<int64_t>(b) * D + D;  // src_off of row 0 is -D + 4 * piece
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+      if (i < NI) {
+        const float* g = (i == 0 && dense_lane) ? dn + src_off[0] : sp + src_off[i];
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(xs + i * (kWave * 4)), 16, 0, 0);
+      }
+    }
+  };
+  const int T = (P + kWave - 1) / kWave;  // pair stores per sample
+  constexpr int DS = (D + kWave - 1) / kWave;  // dense pass-through stores per sample
+  int stores_behind_copy = 0;
+  int b = blockIdx.x * 4 + wave;
+  int iter = 0;
+  auto stamp = [&](int k) {
+    if (ABL == 6 && stamps != nullptr && blockIdx.x < kStampBlocks && iter < kStampIters && lane == 0)
+      stamps[((blockIdx.x * 4 + wave) * kStampIters + iter) * kStampsPerIter + k] = clock64();
+  };
+  if (b < B) issue_copy(b);
+  for (; b < B; b += stride_b, ++iter) {
+    stamp(0);
+    // the copy of sample b has landed once everything but the stores issued after it has retired (an LDS-DMA counts
+    // on the VM counter like a load; operations retire in issue order)
+    vm_wait_all_but(stores_behind_copy);
+    __builtin_amdgcn_wave_barrier();
+    stamp(1);
+    if (ABL == 5) {
+      if (xs[lane] == 1.2345e-31f) out[b] = 1.f;  // keep the copy alive
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (b + stride_b < B) issue_copy(b + stride_b);
+      continue;
+    }
+    float4 xa[NS], xb[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) xa[s] = *reinterpret_cast<const float4*>(xs + row0 * D + 4 * ((4 * s + kq) ^ (row0 & 15)));
+    if (R > 16) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) xb[s] = *reinterpret_cast<const float4*>(xs + row1 * D + 4 * ((4 * s + kq) ^ (row1 & 15)));
+    } else {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) xb[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 dpass = make_float4(0.f, 0.f, 0.f, 0.f);
+    float dscal[DS];  // row 0 is stored unswizzled
+    if (vec_out) {
+      if (dense_lane) dpass = *reinterpret_cast<const float4*>(xs + 4 * lane);
+    } else {
+#pragma unroll
+      for (int t = 0; t < DS; ++t) dscal[t] = xs[min(lane + t * kWave, D - 1)];
+    }
+    // every read of the image has returned before the next copy may overwrite it
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    stamp(2);
+    if (b + stride_b < B) issue_copy(b + stride_b);
+    stamp(3);
+    f32x4 acc00 = {0.f, 0.f, 0.f, 0.f}, acc01 = acc00, acc11 = acc00;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const float a0[4] = {xa[s].x, xa[s].y, xa[s].z, xa[s].w};
+      const float a1[4] = {xb[s].x, xb[s].y, xb[s].z, xb[s].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (ABL == 2) {
+          acc00[0] += a0[e];
+          acc01[0] += a1[e];
+          continue;
+        }
+        acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], a0[e], acc00, 0, 0, 0);
+        acc01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], a1[e], acc01, 0, 0, 0);
+        acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], a1[e], acc11, 0, 0, 0);
+      }
+    }
+    float* orow = out + static_cast<int64_t>(b) * out_stride;
+    if (ABL == 1) {
+      if (acc00[0] + acc01[1] + acc11[2] + dpass.x + dscal[0] == 1.2345e-31f) orow[0] = 1.f;
+      stores_behind_copy = 0;
+      continue;
+    }
+    if (vec_out) {
+      if (dense_lane) st4(orow + lane * 4, dpass);
+    } else {
+#pragma unroll
+      for (int t = 0; t < DS; ++t) vm_store_dword(orow + min(lane + t * kWave, D - 1), dscal[t]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = kq * 4 + q;
+      const int j = r16;
+      if (i < j && j < R) zs[triu_index(i, j, R)] = acc00[q];
+      if (16 + j < R && i < R) zs[triu_index(i, 16 + j, R)] = acc01[q];
+      if (i < j && 16 + j < R) zs[triu_index(16 + i, 16 + j, R)] = acc11[q];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (ABL == 6) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      stamp(4);
+    }
+    constexpr int MAXT = 8;
+    constexpr int MAXQ = 2;
+    if (vec_out) {
+#pragma unroll
+      for (int t = 0; t < MAXQ; ++t) {
+        const int q = lane + t * kWave;
+        if (q < P4 / 4) st4(orow + D + 4 * q, *reinterpret_cast<const float4*>(zs + 4 * q));
+      }
+      stores_behind_copy = 0;  // compiler-generated stores: their number is not ours to count, wait for everything
+    } else {
+      float zv[MAXT];
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t)
+        if (t < T) zv[t] = zs[min(lane + t * kWave, P - 1)];
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t)
+        if (t < T) vm_store_dword(orow + D + min(lane + t * kWave, P - 1), zv[t]);
+      stores_behind_copy = DS + T;
+    }
+    stamp(5);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 template <int NT>  // NT = D / 16 column tiles
 __global__ __launch_bounds__(256, 2) void interaction_bwd_kernel(const float* __restrict__ dense,
                                                                  const float* __restrict__ sparse,
@@ -383,12 +594,17 @@ extern "C" int tbe_dlrm_interaction_forward_f32(const float* dense, const float*
     const char* e = getenv("TBE_INTERACTION_ABLATION");  // tuning runs only
     return e ? atoi(e) : 0;
   }();
-  if (ablation == 1 && D == 128) {
+  static const bool reg_form = [] {
+    const char* e = getenv("TBE_INTERACTION_FORM");  // "reg": the register-operand kernel at every D (tuning runs)
+    return e && e[0] == 'r';
+  }();
+  const bool glds_form = (D == 64 || D == 128) && !reg_form;
+  if (!glds_form && ablation == 1 && D == 128) {
     hipLaunchKernelGGL((interaction_fwd_kernel<128, 1>), grid, dim3(256), lds, st, dense, sparse, out, B, F, out_row_stride);
     TBE_CHECK_LAUNCH("tbe_dlrm_interaction_forward_f32");
     return TBE_OK;
   }
-  if ((ablation == 3 || ablation == 4) && D == 128) {
+  if (!glds_form && (ablation == 3 || ablation == 4) && D == 128) {
     if (ablation == 3)
       hipLaunchKernelGGL((interaction_fwd_kernel<128, 3>), grid, dim3(256), lds, st, dense, sparse, out, B, F, out_row_stride);
     else
@@ -396,8 +612,40 @@ extern "C" int tbe_dlrm_interaction_forward_f32(const float* dense, const float*
     TBE_CHECK_LAUNCH("tbe_dlrm_interaction_forward_f32");
     return TBE_OK;
   }
-  if (ablation == 2 && D == 128) {
+  if (!glds_form && ablation == 2 && D == 128) {
     hipLaunchKernelGGL((interaction_fwd_kernel<128, 2>), grid, dim3(256), lds, st, dense, sparse, out, B, F, out_row_stride);
+    TBE_CHECK_LAUNCH("tbe_dlrm_interaction_forward_f32");
+    return TBE_OK;
+  }
+  if (glds_form) {
+    // LDS-DMA form: one [rows, D] image + the pair block per wave, 2 workgroups per CU
+    const int rpi = 64 / (D / 4);
+    const int rows = (R + rpi - 1) / rpi * rpi;
+    const size_t lds_g = 4 * (static_cast<size_t>(rows) * D + ((P + 3) & ~3)) * sizeof(float);
+    static bool glds_attr = false;
+    if (!glds_attr) {
+      const size_t big = 4 * (static_cast<size_t>(32) * 128 + 496) * sizeof(float);
+      if (!reserve_lds(interaction_fwd_glds_kernel<128>, big) || !reserve_lds(interaction_fwd_glds_kernel<64>, big) ||
+          !reserve_lds(interaction_fwd_glds_kernel<128, 1>, big) || !reserve_lds(interaction_fwd_glds_kernel<128, 2>, big) ||
+          !reserve_lds(interaction_fwd_glds_kernel<128, 5>, big) || !reserve_lds(interaction_fwd_glds_kernel<128, 6>, big)) {
+        set_error("tbe_dlrm_interaction_forward_f32: cannot reserve LDS");
+        return TBE_ERR_LAUNCH;
+      }
+      glds_attr = true;
+    }
+    const dim3 grid_g(static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(want, 256 * 2))));
+    if (D == 128 && ablation == 1)
+      hipLaunchKernelGGL((interaction_fwd_glds_kernel<128, 1>), grid_g, dim3(256), lds_g, st, dense, sparse, out, B, F, out_row_stride, g_interaction_stamps);
+    else if (D == 128 && ablation == 2)
+      hipLaunchKernelGGL((interaction_fwd_glds_kernel<128, 2>), grid_g, dim3(256), lds_g, st, dense, sparse, out, B, F, out_row_stride, g_interaction_stamps);
+    else if (D == 128 && ablation == 6)
+      hipLaunchKernelGGL((interaction_fwd_glds_kernel<128, 6>), grid_g, dim3(256), lds_g, st, dense, sparse, out, B, F, out_row_stride, g_interaction_stamps);
+    else if (D == 128 && ablation == 5)
+      hipLaunchKernelGGL((interaction_fwd_glds_kernel<128, 5>), grid_g, dim3(256), lds_g, st, dense, sparse, out, B, F, out_row_stride, g_interaction_stamps);
+    else if (D == 128)
+      hipLaunchKernelGGL(interaction_fwd_glds_kernel<128>, grid_g, dim3(256), lds_g, st, dense, sparse, out, B, F, out_row_stride, g_interaction_stamps);
+    else
+      hipLaunchKernelGGL(interaction_fwd_glds_kernel<64>, grid_g, dim3(256), lds_g, st, dense, sparse, out, B, F, out_row_stride, g_interaction_stamps);
     TBE_CHECK_LAUNCH("tbe_dlrm_interaction_forward_f32");
     return TBE_OK;
   }
@@ -411,6 +659,11 @@ extern "C" int tbe_dlrm_interaction_forward_f32(const float* dense, const float*
   }
 #undef TBE_IF
   TBE_CHECK_LAUNCH("tbe_dlrm_interaction_forward_f32");
+  return TBE_OK;
+}
+
+extern "C" int tbe_debug_set_interaction_stamps(void* device_buffer) {
+  g_interaction_stamps = static_cast<uint64_t*>(device_buffer);
   return TBE_OK;
 }
 

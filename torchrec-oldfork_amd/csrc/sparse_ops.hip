@@ -383,6 +383,17 @@ __global__ __launch_bounds__(256) void dense_to_jagged_2d_kernel(const float* __
   }
 }
 
+// Rows `rows[y]` of a [*, row_vecs] matrix of 16-byte vectors into row y of a dense output: the send-order gather of the
+// input exchange (torchrec/distributed/dist_data.py:257-263 permutes whole KJTs for this; fixed-length streams need only rows).
+__global__ __launch_bounds__(256) void copy_rows_kernel(const uint4* __restrict__ src, const int32_t* __restrict__ rows,
+                                                       int64_t row_vecs, uint4* __restrict__ dst) {
+  const uint4* in = src + static_cast<int64_t>(rows[blockIdx.y]) * row_vecs;
+  uint4* out = dst + static_cast<int64_t>(blockIdx.y) * row_vecs;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < row_vecs;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+    out[i] = in[i];
+}
+
 __global__ __launch_bounds__(256) void offsets_range_kernel(const int64_t* __restrict__ offsets, int64_t n,
                                                            int64_t range_size, int64_t* __restrict__ out) {
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < range_size;
@@ -675,5 +686,23 @@ extern "C" int tbe_offsets_range(const int64_t* offsets, int64_t n, int64_t rang
   hipLaunchKernelGGL(offsets_range_kernel, dim3(grid_for(range_size)), dim3(256), 0, static_cast<hipStream_t>(stream), offsets, n,
                      range_size, out);
   TBE_CHECK_LAUNCH("tbe_offsets_range");
+  return TBE_OK;
+}
+
+extern "C" int tbe_copy_rows(const void* src, int64_t src_rows, const int32_t* rows, int32_t n_rows, int64_t row_bytes, void* dst,
+                             void* stream) {
+  TBE_REQUIRE(n_rows >= 0 && src_rows >= 0 && row_bytes >= 0, "tbe_copy_rows: bad sizes");
+  if (n_rows == 0 || row_bytes == 0) return TBE_OK;
+  TBE_REQUIRE(src && rows && dst, "tbe_copy_rows: null pointer");
+  TBE_REQUIRE(n_rows <= 65535, "tbe_copy_rows: more than 65535 rows");
+  TBE_REQUIRE(row_bytes % 16 == 0 && reinterpret_cast<uintptr_t>(src) % 16 == 0 && reinterpret_cast<uintptr_t>(dst) % 16 == 0,
+              "tbe_copy_rows: rows must be multiples of 16 bytes at 16-byte aligned addresses");
+  const int64_t row_vecs = row_bytes / 16;
+  const int64_t per_row = (row_vecs + 255) / 256;
+  // ~8 vectors per thread once the launch fills the chip
+  const int64_t want = std::max<int64_t>(1, std::min<int64_t>(per_row, std::max<int64_t>(2048 / n_rows, (per_row + 7) / 8)));
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(static_cast<unsigned>(want), static_cast<unsigned>(n_rows)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const uint4*>(src), rows, row_vecs, static_cast<uint4*>(dst));
+  TBE_CHECK_LAUNCH("tbe_copy_rows");
   return TBE_OK;
 }

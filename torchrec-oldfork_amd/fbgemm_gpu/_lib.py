@@ -82,6 +82,7 @@ SIGNATURES = {
     ),
     "tbe_debug_sort_timeouts": (ctypes.c_int, [ctypes.POINTER(c_i64)]),
     "tbe_debug_set_sort_stamps": (ctypes.c_int, [c_void_p]),
+    "tbe_debug_set_interaction_stamps": (ctypes.c_int, [c_void_p]),
     "tbe_backward_apply_f32": (
         ctypes.c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32,
@@ -142,6 +143,7 @@ SIGNATURES = {
     "tbe_dense_to_jagged_2d_f32": (
         ctypes.c_int, [c_void_p, c_void_p, c_i32, c_i32, c_i32, c_i64, c_void_p, c_void_p]),
     "tbe_offsets_range": (ctypes.c_int, [c_void_p, c_i64, c_i64, c_void_p, c_void_p]),
+    "tbe_copy_rows": (ctypes.c_int, [c_void_p, c_i64, c_void_p, c_i32, c_i64, c_void_p, c_void_p]),
 }
 
 _lib: Optional[ctypes.CDLL] = None
@@ -201,7 +203,10 @@ def require_gpu(*tensors: Optional[torch.Tensor]) -> torch.device:
 
 
 def stream_ptr(dev: torch.device) -> int:
-    return torch.cuda.current_stream(dev).cuda_stream
+    """hipStream_t of torch's current stream on `dev` (the raw-handle call: torch.cuda.current_stream() builds a Stream
+    object per call, ~8 us of host time, and a train step asks a dozen times)."""
+    idx = dev.index
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device() if idx is None else idx)
 
 
 def workspace(nbytes: int, dev: torch.device) -> torch.Tensor:

@@ -434,13 +434,18 @@ class _TBEBase(nn.Module):
                 self._buffers[n] = self._buffers[n].pin_memory()
         self._pinned_key = tuple(self._buffers[n].data_ptr() for n in names)
 
+    def _state_key(self) -> Tuple:
+        """Addresses of the flat optimizer-state buffers (what _state_ptrs() is derived from)."""
+        return ()
+
     def _real_layout(self) -> _Layout:
         self._ensure_pinned()
-        s0, s1 = self._state_ptrs()
-        key = (self._storage_key(), tuple(s0 or ()), tuple(s1 or ()), self._row_windows, self._feature_pooling)
+        # per step: a handful of data_ptr() calls; the per-table address lists are rebuilt only when a buffer moved
+        key = (self._storage_key(), self._state_key(), self._row_windows, self._feature_pooling)
         lay = self._layout
         if lay.key == key:
             return lay
+        s0, s1 = self._state_ptrs()
         dev = self.current_device
         base = {p: self._flat_weights(p).data_ptr() for p in ("dev", "uvm")}
         wptr = [base[self.placement[t]] + 4 * self.weights_offsets[t] for t in range(self.T)]
@@ -903,6 +908,13 @@ class SplitTableBatchedEmbeddingBagsCodegen(_TBEBase):
 
     def _state_flat(self, name: str, placement: str) -> torch.Tensor:
         return getattr(self, f"{name}_{placement}")
+
+    def _state_key(self):
+        code = _OPT_CODE[self.optimizer]
+        if code == 0:
+            return ()
+        names = ("momentum1", "momentum2") if code == 2 else ("momentum1",)
+        return tuple(self._state_flat(n, p).data_ptr() for n in names for p in ("dev", "uvm"))
 
     def _state_ptrs(self):
         code = _OPT_CODE[self.optimizer]

@@ -17,7 +17,22 @@ _def.define("a2a_pooled_unpack(Tensor recv, Tensor dim_sum_per_rank, int B_local
 _def.define("a2a_pooled_pack(Tensor grad, Tensor dim_sum_per_rank, bool vec, float scale) -> Tensor")
 _def.define("relu_backward_bias_grad(Tensor grad_out, Tensor act) -> (Tensor, Tensor)")
 _def.define("weighted_colsum(Tensor x, Tensor w) -> Tensor")
+_def.define("copy_rows(Tensor src, Tensor rows) -> Tensor")
 _impl = torch.library.Library("tbe_hip", "IMPL", "CUDA")
+
+
+def _copy_rows(src, rows):
+    """src[rows] for a contiguous 2-D `src` whose rows are multiples of 16 bytes and a device int32 `rows`
+    (csrc/sparse_ops.hip copy_rows_kernel)."""
+    dev = require_gpu(src, rows)
+    if src.dim() != 2 or not src.is_contiguous() or rows.dtype != torch.int32 or rows.dim() != 1:
+        raise RuntimeError(f"copy_rows: need a contiguous 2-D src and int32 rows, got {tuple(src.shape)} / {rows.dtype}")
+    out = src.new_empty((rows.numel(), src.shape[1]))
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        check(lib.tbe_copy_rows(ptr(src), src.shape[0], ptr(rows), rows.numel(), src.shape[1] * src.element_size(), ptr(out),
+                                stream_ptr(dev)), "tbe_copy_rows")
+    return out
 
 
 def _weighted_colsum(x, w):
@@ -115,6 +130,7 @@ def _pack(grad, feat_out_col, feat_src, feat_slab_col, slab_offset, slab_stride,
 
 _impl.impl("relu_backward_bias_grad", _relu_backward_bias_grad)
 _impl.impl("weighted_colsum", _weighted_colsum)
+_impl.impl("copy_rows", _copy_rows)
 _impl.impl("pooled_exchange_unpack", _unpack)
 _impl.impl("pooled_exchange_unpack_into", _unpack_into)
 _impl.impl("pooled_exchange_pack", _pack)

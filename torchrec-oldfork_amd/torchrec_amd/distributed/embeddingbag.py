@@ -54,18 +54,26 @@ def set_gradient_division(val: bool) -> None:
     GRADIENT_DIVISION = val
 
 
-def _gather_rows(mat: torch.Tensor, order: List[int]) -> torch.Tensor:
-    """Rows `order` of a [keys, B * L] id / weight matrix as one contiguous [len(order), B * L] block.  A cat of row
-    views (one batched-copy launch); torch.index_select picks a per-element kernel for this shape that needs 87 us for
-    26 x 8192 ids (rocprof, MI355X) where the copy takes ~5."""
+def _gather_rows(mat: torch.Tensor, order: List[int], order_dev: torch.Tensor) -> torch.Tensor:
+    """Rows `order` of a [keys, B * L] id / weight matrix as one contiguous [len(order), B * L] block (`order_dev`: the same
+    list as a device int32 tensor).  On the GPU one launch of csrc/sparse_ops.hip copy_rows_kernel (16-byte vectors):
+    torch.index_select picks a per-element kernel for this shape (87 us for 26 x 8192 ids, rocprof on MI355X) and a cat of
+    row slices is no better (76 us)."""
     if not order:
         return mat.new_empty((0, mat.shape[1]))
-    runs, start = [], 0  # consecutive rows travel as one slice
-    for i in range(1, len(order) + 1):
-        if i == len(order) or order[i] != order[i - 1] + 1:
-            runs.append(mat[order[start]:order[i - 1] + 1])
-            start = i
-    return runs[0] if len(runs) == 1 else torch.cat(runs, dim=0)
+    if order == list(range(order[0], order[0] + len(order))):
+        return mat[order[0]:order[0] + len(order)]
+    if os.environ.get("TORCHREC_AMD_GATHER") == "cat":
+        runs, start = [], 0
+        for i in range(1, len(order) + 1):
+            if i == len(order) or order[i] != order[i - 1] + 1:
+                runs.append(mat[order[start]:order[i - 1] + 1])
+                start = i
+        return torch.cat(runs, dim=0)
+    if mat.is_cuda and mat.is_contiguous() and (mat.shape[1] * mat.element_size()) % 16 == 0 and mat.data_ptr() % 16 == 0:
+        from . import _device_ops  # noqa: F401  (registers torch.ops.tbe_hip.*)
+        return torch.ops.tbe_hip.copy_rows(mat, order_dev)
+    return mat.index_select(0, order_dev.long())
 
 
 def _default_dp_tbe_factory(specs, ftm, pooling_mode, device):
@@ -618,7 +626,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
             if missing:
                 raise KeyError(f"KeyedJaggedTensor is missing features {missing[:3]}...")
             order = [pos[self._feature_names[g]] for g in self._send_feature_order]
-            hit = (order, torch.tensor(order, dtype=torch.int64, device=self._device))
+            hit = (order, torch.tensor(order, dtype=torch.int32, device=self._device))
             self._kjt_cache[ck] = hit
         return hit
 
@@ -632,7 +640,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
         if hit is None:
             pos = {k: i for i, k in enumerate(keys)}
             order = [pos[self._feature_names[g]] for g in self._dp_feats]
-            hit = (order, torch.tensor(order, dtype=torch.int64, device=self._device))
+            hit = (order, torch.tensor(order, dtype=torch.int32, device=self._device))
             self._kjt_cache[ck] = hit
         order, order_t = hit
         B = features.stride()
@@ -641,8 +649,8 @@ class ShardedEmbeddingBagCollection(nn.Module):
         if fixed is not None and len(set(fixed)) == 1 and fixed[0] > 0:
             L = fixed[0]
             nkeys = len(keys)
-            v = _gather_rows(features.values().view(nkeys, B * L), order).reshape(-1)
-            w = _gather_rows(weights.view(nkeys, B * L), order).reshape(-1) if weights is not None else None
+            v = _gather_rows(features.values().view(nkeys, B * L), order, order_t).reshape(-1)
+            w = _gather_rows(weights.view(nkeys, B * L), order, order_t).reshape(-1) if weights is not None else None
             ck2 = ("dpoff", B, L)
             offs = self._kjt_cache.get(ck2)
             if offs is None:
@@ -665,8 +673,8 @@ class ShardedEmbeddingBagCollection(nn.Module):
                 send_v = features.values().view(nkeys, B * L)
                 send_w = weights.view(nkeys, B * L) if weights is not None else None
             else:
-                send_v = _gather_rows(features.values().view(nkeys, B * L), order)
-                send_w = _gather_rows(weights.view(nkeys, B * L), order) if weights is not None else None
+                send_v = _gather_rows(features.values().view(nkeys, B * L), order, order_t)
+                send_w = _gather_rows(weights.view(nkeys, B * L), order, order_t) if weights is not None else None
             in_splits = [n * B * L for n in self._send_feats_per_rank]
             out_splits = [self._F_local * B * L] * W
             if self._exchange:

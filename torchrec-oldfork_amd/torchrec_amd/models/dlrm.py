@@ -314,6 +314,9 @@ class DLRMTrain(nn.Module):
         """After backward: folds the autograd gradients of the non-graphed dense parameters into the flat
         buffer, all-reduces the rest of it (bottom segment + those), waits, and attaches the slices as
         `.grad` (every rank then holds the rank-averaged gradient, as under DistributedDataParallel)."""
+        from ..modules.mlp import _WgradOverlap
+
+        _WgradOverlap.join()  # weight gradients computed on the side stream (eager steps; modules/mlp.py)
         st = getattr(self, "_flat_dense", None)
         if st is None:
             return

@@ -6,6 +6,53 @@ import torch
 from torch import nn
 
 
+class _WgradOverlap:
+    """Weight-gradient GEMMs on a side stream (eager steps only).
+
+    dW = dY^T X of a Linear is needed by nobody until the optimizer runs, while the chain the backward waits for —
+    dX = dY W, the ReLU-backward pass, the interaction backward, the embedding backward — alternates MFMA-bound GEMMs
+    with HBM-bound passes.  With this switch on, `_LinearSplitKWgrad.backward` enqueues dW on a second stream (ordered
+    after dY by an event), accumulates it into `weight.grad` there and hands autograd no weight gradient; the GEMM then
+    shares the chip with whatever the main stream runs next.  The OWNER of the train loop must call `join()` after
+    backward and before the optimizer reads the gradients (TrainPipelineSparseDist does, through
+    DLRMTrain.finish_dense_grads) — hence opt-in.  Not for modules wrapped in DistributedDataParallel (its hooks
+    never see these gradients) and not inside a HIP-graph capture (the graphed segments keep their own order)."""
+
+    stream: Optional[torch.cuda.Stream] = None
+    on: bool = False
+    pending: List[torch.cuda.Event] = []
+
+    @classmethod
+    def enable(cls, device: torch.device) -> None:
+        """Switch on for backward passes started from now on (the caller brackets ONE backward: enable, backward,
+        join / disable)."""
+        if cls.stream is None or cls.stream.device != device:
+            import os
+
+            # numerically larger = lower priority; the runtime clamps to what the device offers
+            cls.stream = torch.cuda.Stream(device, priority=int(os.environ.get("TORCHREC_AMD_WGRAD_PRIORITY", "0")))
+        cls.on = True
+
+    @classmethod
+    def disable(cls) -> None:
+        cls.join()
+        cls.on = False
+
+    @classmethod
+    def join(cls) -> None:
+        """The current stream waits for every weight gradient enqueued so far."""
+        if cls.pending:
+            cur = torch.cuda.current_stream()
+            for ev in cls.pending:
+                cur.wait_event(ev)
+            cls.pending = []
+
+    @classmethod
+    def active_for(cls, t: torch.Tensor) -> bool:
+        return (cls.on and cls.stream is not None and t.is_cuda and t.device == cls.stream.device
+                and not torch.cuda.is_current_stream_capturing())
+
+
 class _LinearSplitKWgrad(torch.autograd.Function):
     """y = x W^T + b with the weight gradient computed as a batched GEMM over batch chunks.
 
@@ -20,6 +67,7 @@ class _LinearSplitKWgrad(torch.autograd.Function):
         ctx.chunks = chunks
         ctx.has_bias = bias is not None
         ctx.fuse_relu = fuse_relu
+        ctx.weight_param = weight if (weight.is_leaf and weight.requires_grad) else None
         if fuse_relu:
             # bias + ReLU in the GEMM epilogue (hipBLASLt): no separate activation kernel
             out = torch._addmm_activation(bias, x, weight.t(), use_gelu=False)
@@ -53,10 +101,33 @@ class _LinearSplitKWgrad(torch.autograd.Function):
                 gx = gy @ weight
         B = x.shape[0]
         c = ctx.chunks
-        if c > 1 and B % c == 0:
-            gw = torch.bmm(gy.view(c, B // c, -1).transpose(1, 2), x.view(c, B // c, -1)).sum(dim=0)
+
+        def wgrad():
+            if c > 1 and B % c == 0:
+                return torch.bmm(gy.view(c, B // c, -1).transpose(1, 2), x.view(c, B // c, -1)).sum(dim=0)
+            return gy.t() @ x
+
+        w = ctx.weight_param
+        if w is not None and ctx.needs_input_grad[1] and _WgradOverlap.active_for(gy):
+            side, cur = _WgradOverlap.stream, torch.cuda.current_stream()
+            ready = torch.cuda.Event()
+            ready.record(cur)  # dY (and the step's earlier work on this stream) is complete for the side stream
+            side.wait_event(ready)
+            with torch.cuda.stream(side):
+                gw = wgrad()
+                if w.grad is None:
+                    w.grad = gw
+                else:
+                    w.grad.add_(gw)
+                done = torch.cuda.Event()
+                done.record(side)
+            for t in (gy, x):
+                t.record_stream(side)  # freed by autograd on `cur` while the side stream may still read them
+            gw.record_stream(cur)      # read by the optimizer on the main stream after join()
+            _WgradOverlap.pending.append(done)
+            gw = None
         else:
-            gw = gy.t() @ x
+            gw = wgrad()
         if gb is None and ctx.has_bias:
             gb = gy.sum(dim=0)
         return gx, gw, gb, None, None
