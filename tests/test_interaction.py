@@ -70,7 +70,8 @@ def test_dlrm_model_state_dict_keys_and_logits_match_reference_golden():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("pad_rows", [False, True], ids=["dense_rows", "padded_rows"])
-@pytest.mark.parametrize("B,F,D", [(65, 26, 128), (1, 26, 128), (300, 2, 16), (17, 7, 32), (9, 27, 64), (1030, 26, 128)])
+@pytest.mark.parametrize("B,F,D", [(65, 26, 128), (1, 26, 128), (300, 2, 16), (17, 7, 32), (9, 27, 64), (1030, 26, 128),
+                                   (8192, 26, 128), (4099, 27, 128), (2600, 5, 64), (257, 26, 128)])
 def test_hip_interaction_bit_exact_vs_oracle(B, F, D, pad_rows):
     """pad_rows: the output is a [B, D + P] view of a buffer whose rows are padded to a multiple of 4 floats (16-B
     stores); the gradient comes back both as a dense tensor and as a row-padded view."""
@@ -109,6 +110,25 @@ def test_hip_interaction_bit_exact_vs_oracle(B, F, D, pad_rows):
     ref.backward(torch.from_numpy(go).cuda())
     torch.testing.assert_close(td.grad, td2.grad, rtol=1e-5, atol=1e-4)
     torch.testing.assert_close(ts.grad, ts2.grad, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_interaction_forward_full_batch_matches_torch_formulation():
+    """Full-size launch (batch 65 536, F = 26, D = 128): the last samples of the batch — the last iterations of every
+    wave's sample loop — against the reference's bmm + triu formulation."""
+    import torch
+
+    from torchrec_amd.models.dlrm import _FusedDotInteraction
+
+    dense = torch.randn(65536, 128, device="cuda")
+    sparse = torch.randn(65536, 26, 128, device="cuda")
+    out = _FusedDotInteraction.apply(dense, sparse)
+    for sl in (slice(0, 256), slice(65536 - 512, 65536)):
+        x = torch.cat([dense[sl, None, :], sparse[sl]], dim=1)
+        z = torch.bmm(x, x.transpose(1, 2))
+        iu = torch.triu_indices(27, 27, offset=1, device="cuda")
+        torch.testing.assert_close(out[sl, 128:], z[:, iu[0], iu[1]], rtol=1e-5, atol=1e-4)
+        assert torch.equal(out[sl, :128], dense[sl])
 
 
 @pytest.mark.gpu

@@ -128,16 +128,6 @@ class TrainPipelineSparseDist:
         self._connected = True
 
     def progress(self, dataloader_iter: Iterator) -> Any:
-        import os
-        if os.environ.get("TORCHREC_AMD_MAIN_PRIORITY") and self._device.type == "cuda":  # experiment
-            if not hasattr(self, "_main_stream"):
-                self._main_stream = torch.cuda.Stream(self._device, priority=-1)
-                self._main_stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self._main_stream):
-                return self._progress(dataloader_iter)
-        return self._progress(dataloader_iter)
-
-    def _progress(self, dataloader_iter: Iterator) -> Any:
         if not self._connected:
             self._fill(dataloader_iter)
         if self._batch_i is None:
