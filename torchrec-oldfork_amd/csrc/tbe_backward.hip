@@ -191,7 +191,7 @@ __device__ __forceinline__ float group_sum(float v) {
 // Applies the optimizer to one table row.  `g` = coalesced gradient columns held by this lane,
 // `w` = current weight columns (pre-loaded).  Group-uniform control flow.
 // OPTC >= 0 fixes the optimizer at compile time (smaller live state => more waves per SIMD).
-template <int G, int NV, int OPTC = -1>
+template <int G, int NV, int OPTC = -1, int ABL = 0>
 __device__ __forceinline__ void apply_row(const BwdArgs& a, int f, int64_t local_row, int D,
                                           bool vec, int gl, float* wrow, float4 (&w)[NV],
                                           float4 (&g)[NV]) {
@@ -207,7 +207,7 @@ __device__ __forceinline__ void apply_row(const BwdArgs& a, int f, int64_t local
         r.y = fmaf(-lr, g[v].y, w[v].y);
         r.z = fmaf(-lr, g[v].z, w[v].z);
         r.w = fmaf(-lr, g[v].w, w[v].w);
-        stc(wrow, d, D, vec, r);
+        if (ABL == 0 || r.x == 1.2345e-31f) stc(wrow, d, D, vec, r);  // ABL: tuning runs without the row write
       }
     }
   } else if (optimizer == TBE_OPT_EXACT_ROWWISE_ADAGRAD) {
@@ -309,7 +309,7 @@ struct BwdUnroll {
 
 // FAST: every feature has dim a.fast_D (multiple of 4), SUM pooling, no per-sample weights, every
 // row base 16-B aligned (TBE_FLAG_UNIFORM_ALIGNED from the host) — the Criteo configuration.
-template <typename KeyT, typename PayT, int G, int NV, int OPTC, bool FAST, int U, int MINW>
+template <typename KeyT, typename PayT, int G, int NV, int OPTC, bool FAST, int U, int MINW, int ABL = 0>
 __global__ __launch_bounds__(256, MINW) void bwd_update_kernel(BwdArgs a) {
   constexpr int NG = kWave / G;
   const int lane = threadIdx.x & 63;
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256, MINW) void bwd_update_kernel(BwdArgs a) {
         for (int v = 0; v < NV; ++v) {
           const int d = (v * G + gl) * 4;
           x[u][v] = (val[u] && d < Du[u]) ? ldc(gp, d, Du[u], gvec) : make_float4(0.f, 0.f, 0.f, 0.f);
-          wr[u][v] = (lst[u] && d < Du[u]) ? ldc(wp[u], d, Du[u], vecu[u]) : make_float4(0.f, 0.f, 0.f, 0.f);
+          wr[u][v] = (ABL != 2 && lst[u] && d < Du[u]) ? ldc(wp[u], d, Du[u], vecu[u]) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
 #pragma unroll
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256, MINW) void bwd_update_kernel(BwdArgs a) {
           if (lst[u]) {
             if (started_here) {
               ++nrows;
-              apply_row<G, NV, OPTC>(a, fu[u], lrow[u], Du[u], vecu[u], gl, const_cast<float*>(wp[u]), wr[u], acc);
+              apply_row<G, NV, OPTC, ABL>(a, fu[u], lrow[u], Du[u], vecu[u], gl, const_cast<float*>(wp[u]), wr[u], acc);
             } else {
               float* pf = a.partial_first + chunk * a.max_D_pad;
 #pragma unroll
@@ -719,6 +719,12 @@ static int launch_update(const BwdArgs& a, hipStream_t st) {
         case 2: TBE_UPD(TBE_OPT_EXACT_SGD, true, 2, 8); break;
         case 3: TBE_UPD(TBE_OPT_EXACT_SGD, true, 8, 4); break;
         case 4: TBE_UPD(TBE_OPT_EXACT_SGD, true, 2, 4); break;
+        case 5:  // tuning: no row write
+          hipLaunchKernelGGL((bwd_update_kernel<KeyT, PayT, G, NV, TBE_OPT_EXACT_SGD, true, 4, 4, 1>), dim3(grid), dim3(256), 0, st, a);
+          break;
+        case 6:  // tuning: no row read, no row write (gradient streaming only)
+          hipLaunchKernelGGL((bwd_update_kernel<KeyT, PayT, G, NV, TBE_OPT_EXACT_SGD, true, 4, 4, 2>), dim3(grid), dim3(256), 0, st, a);
+          break;
         default: TBE_UPD(TBE_OPT_EXACT_SGD, true, 4, 4); break;
       }
     } else if (fast && G == 32 && NV == 1 && oc == TBE_OPT_EXACT_ROWWISE_ADAGRAD) {
