@@ -254,7 +254,8 @@ def main(args):
     dense_params = dict(model.named_parameters())
     optimizer = CombinedOptimizer([
         model.fused_optimizer,
-        KeyedOptimizerWrapper(dense_params, lambda p: torch.optim.SGD(p, lr=args.lr))])
+        # torch.optim.SGD, or its one-kernel form when the parameters sit in one flat buffer (N > 1 with HIP graphs)
+        KeyedOptimizerWrapper(dense_params, lambda p: train_model.dense_optimizer(p, lr=args.lr))])
     plan = model.plan
     kinds = [p.sharding_type for p in next(iter(plan.plan.values())).values()]
     n_rw, n_dp = kinds.count("row_wise"), kinds.count("data_parallel")

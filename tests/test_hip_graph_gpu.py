@@ -30,11 +30,14 @@ def _train(hip_graphs: bool, steps: int = 6, flat: bool = False):
     tm = DLRMTrain(ebc, 13, [512, 256, D], [1024, 512, 1], dense_device=dev)
     model = DistributedModelParallel(tm, env=ShardingEnv.from_local(1, 0), device=dev,
                                      sharders=[EmbeddingBagCollectionSharder({"learning_rate": lr})])
-    opt = CombinedOptimizer([model.fused_optimizer,
-                             KeyedOptimizerWrapper(dict(model.named_parameters()), lambda p: torch.optim.SGD(p, lr=lr))])
     data = RandomRecDataset(keys, B, rows, manual_seed=5, num_generated_batches=4, num_batches=steps + 2, device=dev)
     if flat:  # gradients of the graphed segments through one flat buffer (what bench.py does for N > 1)
         tm.capture_hip_graphs(B, flat_grads=True)
+    # as bench.py: the dense optimizer is built after the capture; in flat mode it is the one-kernel FlatSGD
+    dense_opt = KeyedOptimizerWrapper(dict(model.named_parameters()), lambda p: tm.dense_optimizer(p, lr=lr))
+    from torchrec_amd.optim.flat import FlatSGD
+    assert isinstance(dense_opt._optimizer, FlatSGD) == flat
+    opt = CombinedOptimizer([model.fused_optimizer, dense_opt])
     pipe = TrainPipelineSparseDist(model, opt, dev, hip_graphs=hip_graphs and not flat)
     model.train()
     it = iter(data)

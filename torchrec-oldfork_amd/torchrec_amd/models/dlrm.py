@@ -247,8 +247,24 @@ class DLRMTrain(nn.Module):
         dev, B = p.device, batch_size
         F, D = m.sparse_arch.F, m.sparse_arch.D
         dense_in = m.dense_arch.model._mlp[0]._in_size
-        g_dense = GraphedSegment(m.dense_arch, [torch.randn(B, dense_in, device=dev)])
         head = _Head(m.inter_arch, m.over_arch, self.loss_fn)
+        flat_param = None
+        if flat_grads:
+            # the parameters move into ONE flat buffer too (same order as the flat gradient: head, bottom MLP, the
+            # rest), before anything captures their addresses: the dense optimizer becomes one kernel (optim/flat.py)
+            order = ([q for q in head.parameters() if q.requires_grad] + [q for q in m.dense_arch.parameters() if q.requires_grad])
+            seen = {id(q) for q in order}
+            order += [q for q in self.parameters() if q.requires_grad and id(q) not in seen]
+            if all(q.dtype == torch.float32 and q.device == dev for q in order):
+                flat_param = torch.empty(sum(q.numel() for q in order), dtype=torch.float32, device=dev)
+                off = 0
+                with torch.no_grad():
+                    for q in order:
+                        view = flat_param[off:off + q.numel()].view_as(q)
+                        view.copy_(q)
+                        q.data = view
+                        off += q.numel()
+        g_dense = GraphedSegment(m.dense_arch, [torch.randn(B, dense_in, device=dev)])
         g_head = GraphedSegment(
             head, [g_dense.static_outputs[0].detach().requires_grad_(True),
                    torch.randn(B, F, D, device=dev).requires_grad_(True),
@@ -279,7 +295,7 @@ class DLRMTrain(nn.Module):
 
             head_sinks, dense_sinks = views(g_head._params, 0), views(g_dense._params, n_head)
             extra_views = views(extras, n_head + n_dense)
-            state = {"flat": flat, "params": list(g_head._params) + list(g_dense._params) + extras,
+            state = {"flat": flat, "flat_param": flat_param, "params": list(g_head._params) + list(g_dense._params) + extras,
                      "views": head_sinks + dense_sinks + extra_views, "extras": list(zip(extras, extra_views)),
                      "n_head": n_head, "works": [], "pg": process_group, "world": world, "scale": scale}
 
@@ -304,6 +320,20 @@ class DLRMTrain(nn.Module):
         # the head's gradient w.r.t. the bottom-MLP output doubles as the bottom segment's grad_output buffer
         g_dense.capture_backward([g_head.static_grad_inputs[0]], param_grad_sinks=dense_sinks, sink_scale=scale)
         object.__setattr__(self, "_graphs", (B, g_dense, g_head))  # not sub-modules: state_dict keys unchanged
+
+    def dense_optimizer(self, params, lr: float) -> torch.optim.Optimizer:
+        """SGD for the dense parameters (what examples/dlrm/dlrm_main.py:536-540 builds with torch.optim.SGD): one
+        kernel over the flat parameter / gradient buffers when capture_hip_graphs(flat_grads=True) has laid them out
+        (optim/flat.py), torch.optim.SGD otherwise.  Call it AFTER capture_hip_graphs."""
+        params = list(params)
+        st = getattr(self, "_flat_dense", None)
+        if (st is not None and st.get("flat_param") is not None and {id(q) for q in st["params"]} <= {id(q) for q in params}
+                and os.environ.get("TORCHREC_AMD_FLAT_SGD", "1") != "0"):
+            from ..optim.flat import FlatSGD
+
+            return FlatSGD(params, lr, flat_param=st["flat_param"], flat_grad=st["flat"], covered=st["params"],
+                           grad_views=st["views"])
+        return torch.optim.SGD(params, lr=lr)
 
     def flat_grad_parameters(self) -> List[nn.Parameter]:
         """Parameters whose gradients travel through the flat buffer (kept out of DDP)."""
