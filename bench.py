@@ -404,6 +404,7 @@ def main(args):
             # (examples/dlrm/README.MD:45, real Criteo data, end to end) — comparable at N = 8 only
             "vs_baseline": round(value / 5497159.68, 3) if world == 8 else None,
             "dtype": "f32", "data": "synthetic", "hip_graphs": hip_graphs, "hip_graphs_note": graphs_note,
+            "explicit_backward_steps": int(getattr(train_model, "explicit_steps", 0)),
             "tuned_gemms": tuned,
             "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 0,
             "backend": dist.get_backend() if dist.is_initialized() else None,

@@ -457,6 +457,8 @@ def _e2e_worker(rank, W, port, ret, hip_graphs=False):
         _e2e_init_tables(model)
         ret[rank] = _e2e_run(model, opt, keys, _e2e_batches(W), rank, W, dev, False)
         assert (model.module._graphs is not None) == bool(hip_graphs)
+        # flat-gradient graph mode runs forward AND backward by hand (DLRMTrain._explicit_step), no autograd engine
+        assert (getattr(model.module, "explicit_steps", 0) == E_STEPS) == (hip_graphs == "flat")
     finally:
         dist.destroy_process_group()
 

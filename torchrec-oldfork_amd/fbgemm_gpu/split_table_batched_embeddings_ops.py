@@ -727,6 +727,18 @@ class _TBEBase(nn.Module):
             )
 
 
+class LookupRecord:
+    """What a lookup made through `lookup_no_autograd` leaves for `backward_no_autograd` (the explicit counterpart of an
+    autograd context: a train step that knows its own schedule — models/dlrm.py, HIP-graph mode — drives forward and
+    backward itself and skips the autograd engine, its per-node Python hand-offs and its worker thread)."""
+
+    __slots__ = ("indices", "offsets", "per_sample_weights", "B", "layout", "prepared")
+
+    def __init__(self, indices, offsets, per_sample_weights, B, layout) -> None:
+        self.indices, self.offsets, self.per_sample_weights, self.B, self.layout = indices, offsets, per_sample_weights, B, layout
+        self.prepared = None
+
+
 class _FusedLookupInto(torch.autograd.Function):
     """Like _FusedLookup, but writes its column blocks into a caller-provided [B, stride] buffer."""
 
@@ -1006,6 +1018,31 @@ class SplitTableBatchedEmbeddingBagsCodegen(_TBEBase):
         self._enforce_bounds_check_mode()
         return out
 
+    def lookup_no_autograd(self, indices: torch.Tensor, offsets: torch.Tensor,
+                           per_sample_weights: Optional[torch.Tensor] = None, into=None):
+        """The training forward without an autograd node: returns (output, LookupRecord).  `into` = (buffer,
+        per-feature offsets, row stride) as in forward_into.  The caller owes exactly one
+        backward_no_autograd(record, grad) per call (the side-stream sort of the backward is already running)."""
+        indices, offsets, per_sample_weights, B = self._check_inputs(indices, offsets, per_sample_weights)
+        if self._cache is not None:
+            indices = self._cache.prefetch(self._real_layout(), indices, offsets, B, True)
+        rec = LookupRecord(indices, offsets, per_sample_weights, B, (into[1], int(into[2])) if into is not None else None)
+        out = self._forward_impl(indices, offsets, per_sample_weights, B, into=into)
+        mode = self.overlap_backward_sort
+        if mode in (True, "1") or (mode == "auto" and indices.numel() <= self.overlap_backward_sort_max_ids):
+            rec.prepared = self._prepare_or_defer(rec, indices, offsets, B, per_sample_weights is not None)
+        self._enforce_bounds_check_mode()
+        return out, rec
+
+    def backward_no_autograd(self, rec: "LookupRecord", grad_out: torch.Tensor) -> None:
+        """Coalesced gradient + fused optimizer update for the lookup `rec` describes (what _FusedLookup.backward does)."""
+        self.iter += 1
+        self._backward_impl(grad_out, rec.indices, rec.offsets, rec.per_sample_weights, rec.B, self._optimizer_struct(),
+                            prepared=rec.prepared, layout=rec.layout)
+        rec.prepared = None
+        if self._cache is not None:
+            self._cache.after_backward()
+
 
 class _DenseLookup(torch.autograd.Function):
     @staticmethod
@@ -1084,3 +1121,18 @@ class DenseTableBatchedEmbeddingBagsCodegen(_TBEBase):
         indices, offsets, per_sample_weights, B = self._check_inputs(indices, offsets, per_sample_weights)
         return _DenseLookupInto.apply(out, self.weights, self, indices, offsets, per_sample_weights, B, out_offsets,
                                       int(row_stride))
+
+    def lookup_no_autograd(self, indices: torch.Tensor, offsets: torch.Tensor,
+                           per_sample_weights: Optional[torch.Tensor] = None, into=None):
+        """Forward without an autograd node: (output, LookupRecord); see the fused class."""
+        indices, offsets, per_sample_weights, B = self._check_inputs(indices, offsets, per_sample_weights)
+        rec = LookupRecord(indices, offsets, per_sample_weights, B, (into[1], int(into[2])) if into is not None else None)
+        return self._forward_impl(indices, offsets, per_sample_weights, B, into=into), rec
+
+    def backward_no_autograd(self, rec: "LookupRecord", grad_out: torch.Tensor) -> torch.Tensor:
+        """The dense gradient of `.weights` for the lookup `rec` describes (what _DenseLookup.backward returns)."""
+        grad_w = torch.zeros_like(self.weights)
+        opt = OptimizerArgs(_OPT_DENSE_GRAD, 0.0, 0.0, 0.0, 0.0, 0.0, 1)
+        self._backward_impl(grad_out, rec.indices, rec.offsets, rec.per_sample_weights, rec.B, opt,
+                            state0_override=self._dense_grad_ptrs(grad_w), layout=rec.layout)
+        return grad_w

@@ -768,8 +768,64 @@ class ShardedEmbeddingBagCollection(nn.Module):
         return _OutputAwaitable(
             lambda: KeyedTensor(keys, lpe, self._dp_fill(_ExchangeWait.apply(recv, state), dist_input)))
 
+    def explicit_step_supported(self, batch_size: int) -> bool:
+        """Whether compute_explicit() can serve a batch of this (per-rank) size: exchange on, a fused module, an output
+        buffer of exactly that batch — the configuration of the HIP-graph train step."""
+        buf = self._output_buffer
+        return (self._exchange and self._emb_module is not None and buf is not None
+                and buf.numel() == batch_size * self._D_total and hasattr(self._emb_module, "lookup_no_autograd")
+                and (self._dp_module is None or hasattr(self._dp_module, "lookup_no_autograd")))
+
+    def compute_explicit(self, dist_input: SparseFeaturesDist) -> "ExplicitLookupStep":
+        """compute_and_output_dist for a caller that runs the backward ITSELF (no autograd nodes): lookup + start of the
+        pooled all-to-all now, `finish()` = wait + unpack (+ replicated tables) into the output buffer,
+        `start_backward(grad)` = pack + gradient all-to-all (+ the replicated tables' backward), `finish_backward()` =
+        the fused backward.  Check explicit_step_supported() first."""
+        if not self.explicit_step_supported(dist_input.batch_size):
+            raise RuntimeError("compute_explicit: not available for this configuration (explicit_step_supported())")
+        return ExplicitLookupStep(self, dist_input)
+
     def forward(self, features: KeyedJaggedTensor) -> Awaitable[KeyedTensor]:
         return self.compute_and_output_dist(self.input_dist(features).wait())
+
+
+class ExplicitLookupStep:
+    """One step of a sharded collection driven without autograd (ShardedEmbeddingBagCollection.compute_explicit)."""
+
+    def __init__(self, owner: "ShardedEmbeddingBagCollection", dist_input: SparseFeaturesDist) -> None:
+        self.o, self.d = owner, dist_input
+        emb, self.rec = owner._emb_module.lookup_no_autograd(dist_input.values, dist_input.offsets, dist_input.weights)
+        self.state = _ExchangeState(owner, dist_input.batch_size)
+        self.state.start_forward(emb)
+        self._emb_keepalive = emb  # read by the collective's stream until finish() has waited for it
+        self.dp_rec = None
+
+    def finish(self) -> torch.Tensor:
+        """[B_local, sum D] pooled embeddings in the collection's key order, inside the output buffer."""
+        o = self.o
+        out = self.state.finish_forward()
+        self._emb_keepalive = None
+        if o._dp_module is not None:
+            v, offs, w = self.d.dp
+            out, self.dp_rec = o._dp_module.lookup_no_autograd(v, offs, w, into=(out, o._dp_out_off, o._D_total))
+        return out
+
+    def start_backward(self, grad_out: torch.Tensor) -> None:
+        """grad_out: [B_local, sum D], contiguous.  Packs and starts the gradient all-to-all, and runs the replicated
+        tables' backward (their dense gradient lands in `.grad` of the module's weights) while it is in flight."""
+        o = self.o
+        self.state.start_backward(grad_out)
+        if self.dp_rec is not None:
+            w = o._dp_module.weights
+            g = o._dp_module.backward_no_autograd(self.dp_rec, grad_out)
+            if w.grad is None:
+                w.grad = g
+            else:
+                w.grad.add_(g)
+            self.dp_rec = None
+
+    def finish_backward(self) -> None:
+        self.o._emb_module.backward_no_autograd(self.rec, self.state.finish_backward())
 
 
 class EmbeddingBagCollectionSharder:

@@ -24,16 +24,26 @@ class _PipelinedEBC(torch.nn.Module):
         self.pipeline = pipeline
         self.embedding_bag_configs = sharded.embedding_bag_configs
 
-    def forward(self, features):
+    def _dist_input(self, features):
         req = self.pipeline._requests.pop(id(self.sharded), None)
         if req is None:
-            return self.sharded(features)
+            return self.sharded.input_dist(features).wait()
         cur = torch.cuda.current_stream()
         with torch.cuda.stream(self.pipeline._data_dist_stream):
             dist_in = req.wait()
         cur.wait_stream(self.pipeline._data_dist_stream)
         dist_in.record_stream(cur)
-        return self.sharded.compute_and_output_dist(dist_in)
+        return dist_in
+
+    def forward(self, features):
+        return self.sharded.compute_and_output_dist(self._dist_input(features))
+
+    def compute_explicit(self, features):
+        """The no-autograd step of the wrapped collection (embeddingbag.py ExplicitLookupStep) on this batch's queued
+        input dist, or None when the collection cannot run it (nothing is consumed then)."""
+        if not hasattr(self.sharded, "compute_explicit") or not self.sharded.explicit_step_supported(features.stride()):
+            return None
+        return self.sharded.compute_explicit(self._dist_input(features))
 
 
 class TrainPipelineSparseDist:
@@ -148,16 +158,32 @@ class TrainPipelineSparseDist:
         fwd_event = torch.cuda.Event() if self._data_dist_stream is not None else None
         if fwd_event is not None:
             fwd_event.record()
-        losses, output = self._model(batch)
-        # input_dist of batch i+1 on the side stream, overlapping fwd/bwd of batch i
-        if self._batch_ip1 is not None:
-            if self._data_dist_stream is not None:
+        started = [False]
+
+        def start_next_input_dist() -> None:
+            # input_dist of batch i+1 on the side stream, overlapping fwd/bwd of batch i
+            if started[0]:
+                return
+            started[0] = True
+            if self._batch_ip1 is not None and self._data_dist_stream is not None:
                 with torch.cuda.stream(self._data_dist_stream):
                     self._data_dist_stream.wait_stream(self._memcpy_stream)
                     self._data_dist_stream.wait_event(fwd_event)
                     self._start_data_dist(self._batch_ip1)
-        if self._model.training:
-            root = self._model.module if isinstance(self._model, DistributedModelParallel) else self._model
+
+        root = self._model.module if isinstance(self._model, DistributedModelParallel) else self._model
+        explicit = self._model.training and hasattr(root, "set_between_forward_and_backward")
+        if explicit:
+            # a model that runs its own backward inside forward (models/dlrm.py explicit step) calls this between the two
+            root.set_between_forward_and_backward(start_next_input_dist)
+        losses, output = self._model(batch)
+        start_next_input_dist()
+        backward_done = explicit and root.take_backward_done()
+        if self._model.training and backward_done:
+            if hasattr(root, "finish_dense_grads"):
+                root.finish_dense_grads()
+            self._optimizer.step()
+        elif self._model.training:
             if self._wgrad_overlap:
                 from ..modules.mlp import _WgradOverlap
 

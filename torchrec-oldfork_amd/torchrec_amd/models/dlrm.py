@@ -51,6 +51,11 @@ class SparseArch(nn.Module):
 _SORT_PLACEMENT = os.environ.get("TORCHREC_AMD_SORT_PLACEMENT", "lookup")
 
 
+# HIP-graph + flat-gradient mode: run forward and backward of a step by hand instead of through the autograd engine
+# (DLRMTrain._explicit_step); TORCHREC_AMD_EXPLICIT_STEP=0 keeps the autograd path.
+_EXPLICIT_STEP = os.environ.get("TORCHREC_AMD_EXPLICIT_STEP", "1") != "0"
+
+
 def _sort_hooks(ebc: nn.Module):
     """(defer, launch) callables of a collection that lets its caller place the backward sort, or (None, None)."""
     if _SORT_PLACEMENT != "head":
@@ -385,11 +390,79 @@ class DLRMTrain(nn.Module):
         for q, v in zip(st["params"], st["views"]):
             q.grad = v
 
+    # ---- explicit train step (HIP-graph + flat-gradient mode): forward AND backward without the autograd engine --------
+    def set_between_forward_and_backward(self, fn) -> None:
+        """A callable the explicit step runs once between its forward and its backward (the train pipeline starts the
+        next batch's input dist there, as it does between `model(batch)` and `loss.backward()` otherwise)."""
+        object.__setattr__(self, "_between", fn)
+
+    def take_backward_done(self) -> bool:
+        """True (once) when the latest forward() already ran the backward: the caller must not call loss.backward()."""
+        done = getattr(self, "_backward_done", False)
+        object.__setattr__(self, "_backward_done", False)
+        return done
+
+    def _explicit_step(self, batch, g_dense, g_head):
+        """One train step of the graphed configuration driven by hand: lookup -> all-to-all || bottom-MLP graph ->
+        head graph (forward + backward replays) -> gradient all-to-all || bottom-MLP backward graph -> embedding
+        backward.  Same kernels, same order of the dependent work as the autograd path; what disappears is the engine
+        (its worker thread, ~12 Python Function nodes and their hand-offs: ~0.25 ms of host time per step, which is the
+        bottleneck of the N > 1 per-rank step on a slow host).  Returns None if the collection cannot run it."""
+        ebc = self.model.sparse_arch.embedding_bag_collection
+        if not hasattr(ebc, "compute_explicit"):
+            return None
+        inner = getattr(ebc, "sharded", ebc)
+        if list(inner._feature_names) != list(self.model.sparse_arch.sparse_feature_names):
+            return None
+        kjt = batch.sparse_features
+        step = (ebc.compute_explicit(kjt) if hasattr(ebc, "sharded")
+                else (ebc.compute_explicit(ebc.input_dist(kjt).wait()) if ebc.explicit_step_supported(kjt.stride()) else None))
+        if step is None:
+            return None
+        B = g_dense.static_inputs[0].shape[0]
+        with torch.no_grad():
+            # bottom MLP (graph) while the pooled all-to-all is in flight
+            if batch.dense_features.data_ptr() != g_dense.static_inputs[0].data_ptr():
+                g_dense.static_inputs[0].copy_(batch.dense_features)
+            g_dense.fwd_graph.replay()
+            pooled = step.finish()  # written into the head segment's static input by the collection
+            if pooled.data_ptr() != g_head.static_inputs[1].data_ptr():
+                g_head.static_inputs[1].copy_(pooled.view_as(g_head.static_inputs[1]))
+            g_head.static_inputs[2].copy_(batch.labels)  # int64 -> float32
+            g_head.fwd_graph.replay()
+            loss, logits = g_head.static_outputs[0], g_head.static_outputs[1]
+            between = getattr(self, "_between", None)
+            if between is not None:
+                between()
+            # backward: d(loss) = 1
+            ones = getattr(self, "_loss_grad_ready", False)
+            if not ones:
+                g_head.static_grad_outputs[0].fill_(1.0)
+                object.__setattr__(self, "_loss_grad_ready", True)
+            g_head.bwd_graph.replay()
+            if g_head.after_backward is not None:
+                g_head.after_backward()
+            step.start_backward(g_head.static_grad_inputs[1].view(B, -1))
+            g_dense.bwd_graph.replay()  # its grad_output buffer IS the head's gradient w.r.t. the bottom-MLP output
+            if g_dense.after_backward is not None:
+                g_dense.after_backward()
+            step.finish_backward()
+        object.__setattr__(self, "_backward_done", True)
+        object.__setattr__(self, "explicit_steps", getattr(self, "explicit_steps", 0) + 1)  # for tests / bench.py's line
+        return loss.detach(), (loss.detach(), logits.detach(), batch.labels.detach())
+
     def forward(self, batch) -> Tuple[torch.Tensor, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
         g = self._graphs
         if (g is not None and self.training and torch.is_grad_enabled()
                 and batch.dense_features.shape[0] == g[0] and batch.dense_features.is_cuda):
             _, g_dense, g_head = g
+            if (getattr(self, "_flat_dense", None) is not None and getattr(self, "_between", None) is not None
+                    and _EXPLICIT_STEP):
+                # only under an owner that asked for it (set_between_forward_and_backward) and will skip loss.backward()
+                out = self._explicit_step(batch, g_dense, g_head)
+                object.__setattr__(self, "_between", None)
+                if out is not None:
+                    return out
             defer, launch = _sort_hooks(self.model.sparse_arch.embedding_bag_collection)
             if defer is not None:
                 defer(True)
@@ -398,6 +471,7 @@ class DLRMTrain(nn.Module):
             embedded_sparse = self.model.sparse_arch.finish(pending)
             if launch is not None:
                 launch()  # beside the head segment (interaction + over arch), after the lookup and the exchange
+            object.__setattr__(self, "_loss_grad_ready", False)  # autograd writes whatever d(loss) the caller backpropagates
             loss, logits = g_head(embedded_dense, embedded_sparse, batch.labels.float())
             return loss, (loss.detach(), logits.detach(), batch.labels.detach())
         logits = self.model(batch.dense_features, batch.sparse_features).squeeze(-1)
