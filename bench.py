@@ -237,8 +237,7 @@ def main(args):
         # With a process group the segments' gradients travel through ONE flat buffer that is all-reduced
         # per segment, instead of DDP's per-parameter bucket copies (models/dlrm.py)
         try:
-            train_model.capture_hip_graphs(B_local, flat_grads=env.process_group is not None,
-                                           process_group=env.process_group)
+            train_model.capture_hip_graphs(B_local, flat_grads=True, process_group=env.process_group)
         except Exception as e:  # measured run must not die on a capture problem: run the segments eagerly
             print(f"[bench] HIP-graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr, flush=True)
             graphs_note = f"FELL BACK to eager: capture failed with {type(e).__name__}: {str(e)[:200]}"

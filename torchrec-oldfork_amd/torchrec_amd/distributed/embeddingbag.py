@@ -769,10 +769,10 @@ class ShardedEmbeddingBagCollection(nn.Module):
             lambda: KeyedTensor(keys, lpe, self._dp_fill(_ExchangeWait.apply(recv, state), dist_input)))
 
     def explicit_step_supported(self, batch_size: int) -> bool:
-        """Whether compute_explicit() can serve a batch of this (per-rank) size: exchange on, a fused module, an output
-        buffer of exactly that batch — the configuration of the HIP-graph train step."""
+        """Whether compute_explicit() can serve a batch of this (per-rank) size: a fused module and an output buffer of
+        exactly that batch — the configuration of the HIP-graph train step (with or without the exchange)."""
         buf = self._output_buffer
-        return (self._exchange and self._emb_module is not None and buf is not None
+        return (self._emb_module is not None and buf is not None
                 and buf.numel() == batch_size * self._D_total and hasattr(self._emb_module, "lookup_no_autograd")
                 and (self._dp_module is None or hasattr(self._dp_module, "lookup_no_autograd")))
 
@@ -790,31 +790,42 @@ class ShardedEmbeddingBagCollection(nn.Module):
 
 
 class ExplicitLookupStep:
-    """One step of a sharded collection driven without autograd (ShardedEmbeddingBagCollection.compute_explicit)."""
+    """One step of a sharded collection driven without autograd (ShardedEmbeddingBagCollection.compute_explicit).
+    With the exchange: lookup in all-to-all layout -> pooled all-to-all -> unpack into the output buffer; without
+    (one rank): the lookup writes its column blocks of the output buffer directly."""
 
     def __init__(self, owner: "ShardedEmbeddingBagCollection", dist_input: SparseFeaturesDist) -> None:
         self.o, self.d = owner, dist_input
-        emb, self.rec = owner._emb_module.lookup_no_autograd(dist_input.values, dist_input.offsets, dist_input.weights)
-        self.state = _ExchangeState(owner, dist_input.batch_size)
-        self.state.start_forward(emb)
-        self._emb_keepalive = emb  # read by the collective's stream until finish() has waited for it
         self.dp_rec = None
+        self.state: Optional[_ExchangeState] = None
+        self._grad: Optional[torch.Tensor] = None
+        if owner._exchange:
+            emb, self.rec = owner._emb_module.lookup_no_autograd(dist_input.values, dist_input.offsets, dist_input.weights)
+            self.state = _ExchangeState(owner, dist_input.batch_size)
+            self.state.start_forward(emb)
+            self._out = None
+        else:
+            out = owner._alias_output_buffer(dist_input.batch_size)
+            self._out, self.rec = owner._emb_module.lookup_no_autograd(
+                dist_input.values, dist_input.offsets, dist_input.weights, into=(out, owner._sharded_out_off, owner._D_total))
 
     def finish(self) -> torch.Tensor:
         """[B_local, sum D] pooled embeddings in the collection's key order, inside the output buffer."""
         o = self.o
-        out = self.state.finish_forward()
-        self._emb_keepalive = None
+        out = self.state.finish_forward() if self.state is not None else self._out
         if o._dp_module is not None:
             v, offs, w = self.d.dp
             out, self.dp_rec = o._dp_module.lookup_no_autograd(v, offs, w, into=(out, o._dp_out_off, o._D_total))
         return out
 
     def start_backward(self, grad_out: torch.Tensor) -> None:
-        """grad_out: [B_local, sum D], contiguous.  Packs and starts the gradient all-to-all, and runs the replicated
-        tables' backward (their dense gradient lands in `.grad` of the module's weights) while it is in flight."""
+        """grad_out: [B_local, sum D], contiguous.  Packs and starts the gradient all-to-all (if any), and runs the
+        replicated tables' backward (their dense gradient lands in `.grad` of the module's weights) meanwhile."""
         o = self.o
-        self.state.start_backward(grad_out)
+        if self.state is not None:
+            self.state.start_backward(grad_out)
+        else:
+            self._grad = grad_out
         if self.dp_rec is not None:
             w = o._dp_module.weights
             g = o._dp_module.backward_no_autograd(self.dp_rec, grad_out)
@@ -825,7 +836,9 @@ class ExplicitLookupStep:
             self.dp_rec = None
 
     def finish_backward(self) -> None:
-        self.o._emb_module.backward_no_autograd(self.rec, self.state.finish_backward())
+        grad = self.state.finish_backward() if self.state is not None else self._grad
+        self._grad = None
+        self.o._emb_module.backward_no_autograd(self.rec, grad)
 
 
 class EmbeddingBagCollectionSharder:
