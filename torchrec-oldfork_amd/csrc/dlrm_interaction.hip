@@ -426,7 +426,6 @@ __global__ __launch_bounds__(256, 2) void interaction_bwd_kernel(const float* __
   const int wave = threadIdx.x >> 6;
   const int R = F + 1;
   const int P = R * (R - 1) / 2;
-  const int OUT = D + P;
   float* xs = smem + wave * (XROWS * XS + 32 * GS);
   float* gs = xs + XROWS * XS;
   const int r16 = lane & 15;
