@@ -47,6 +47,8 @@ class _Replay(torch.autograd.Function):
             if s is not None and g is not None and g.data_ptr() != s.data_ptr():
                 s.copy_(g)
         seg.bwd_graph.replay()
+        if getattr(seg, "bwd_graph2", None) is not None:
+            seg.bwd_graph2.replay()  # deferred weight gradients (capture_backward(defer_wgrad=True))
         if seg.param_grad_sinks is not None:
             # parameter gradients were written (scaled) into the caller's flat buffer inside the graph;
             # autograd gets none, the owner of the buffer is told they are ready
@@ -108,12 +110,19 @@ class GraphedSegment(nn.Module):
         return self.static_inputs[i]
 
     def capture_backward(self, grad_output_buffers: Optional[Sequence[Optional[torch.Tensor]]] = None,
-                         param_grad_sinks: Optional[Sequence[torch.Tensor]] = None, sink_scale: float = 1.0) -> None:
+                         param_grad_sinks: Optional[Sequence[torch.Tensor]] = None, sink_scale: float = 1.0,
+                         defer_wgrad: bool = False) -> None:
         """Captures d(outputs)/d(inputs, parameters).  `grad_output_buffers[i]` lets a downstream
         segment's static input-gradient buffer double as this segment's output-gradient buffer.
         `param_grad_sinks[j]` (one per parameter, in `parameters()` order): the graph itself writes
         `sink_scale * d/d(param j)` there — e.g. views of one flat buffer that is all-reduced as a whole —
-        and autograd receives no parameter gradients from this segment."""
+        and autograd receives no parameter gradients from this segment.
+        `defer_wgrad`: the weight-gradient GEMMs of the segment's Linear layers (modules/mlp.py) and the writes into the
+        sinks go into a SECOND graph, `bwd_graph2`; `bwd_graph` then ends with the input gradients, and an owner that
+        drives the step itself can start what depends on them (the embedding-gradient all-to-all) before it replays the
+        second graph.  `_Replay.backward` replays both back to back."""
+        from ..modules.mlp import _DeferredWgrad
+
         outs = self.static_outputs
         bufs = list(grad_output_buffers) if grad_output_buffers is not None else [None] * len(outs)
         self.static_grad_outputs = [
@@ -121,35 +130,56 @@ class GraphedSegment(nn.Module):
             for i, o in enumerate(outs)]
         need = [o for o in outs if o.requires_grad]
         targets = self._grad_targets()
+        n_in = sum(1 for x in self.static_inputs if x.requires_grad)
+        if param_grad_sinks is not None and len(param_grad_sinks) != len(self._params):
+            raise ValueError("one gradient sink per parameter")
+
+        def write_sinks(pg_) -> None:
+            sinks = list(param_grad_sinks)
+            consecutive = all(s_.is_contiguous() for s_ in sinks) and all(
+                sinks[i + 1].data_ptr() == sinks[i].data_ptr() + sinks[i].numel() * sinks[i].element_size()
+                for i in range(len(sinks) - 1))
+            if consecutive and sinks and all(g is not None for g in pg_):
+                # the sinks are consecutive slices of ONE flat buffer: one batched copy + one scale instead of
+                # a kernel per parameter (16 launches of ~5 us per step at the 8-GPU per-rank batch)
+                total = sum(s_.numel() for s_ in sinks)
+                flat_slice = torch.as_strided(sinks[0], (total,), (1,), sinks[0].storage_offset())
+                torch.cat([g.reshape(-1) for g in pg_], out=flat_slice)
+                if sink_scale != 1.0:
+                    flat_slice.mul_(sink_scale)
+            else:
+                for g, sink in zip(pg_, sinks):
+                    if g is None:
+                        sink.zero_()
+                    else:
+                        torch.mul(g, sink_scale, out=sink)
+            self.param_grad_sinks = sinks
+
         self.bwd_graph = torch.cuda.CUDAGraph()
+        self.bwd_graph2: Optional[torch.cuda.CUDAGraph] = None
         self._stream.synchronize()
+        stash = []
         with torch.cuda.graph(self.bwd_graph, pool=self._pool, stream=self._stream, capture_error_mode="thread_local"):
-            grads = torch.autograd.grad(need, targets, [g for g in self.static_grad_outputs if g is not None],
-                                        allow_unused=True)
-            if param_grad_sinks is not None:
-                n_in = sum(1 for x in self.static_inputs if x.requires_grad)
-                if len(param_grad_sinks) != len(self._params):
-                    raise ValueError("one gradient sink per parameter")
-                pg_ = list(grads[n_in:])
-                sinks = list(param_grad_sinks)
-                consecutive = all(s_.is_contiguous() for s_ in sinks) and all(
-                    sinks[i + 1].data_ptr() == sinks[i].data_ptr() + sinks[i].numel() * sinks[i].element_size()
-                    for i in range(len(sinks) - 1))
-                if consecutive and sinks and all(g is not None for g in pg_):
-                    # the sinks are consecutive slices of ONE flat buffer: one batched copy + one scale instead of
-                    # a kernel per parameter (16 launches of ~5 us per step at the 8-GPU per-rank batch)
-                    total = sum(s_.numel() for s_ in sinks)
-                    flat_slice = torch.as_strided(sinks[0], (total,), (1,), sinks[0].storage_offset())
-                    torch.cat([g.reshape(-1) for g in pg_], out=flat_slice)
-                    if sink_scale != 1.0:
-                        flat_slice.mul_(sink_scale)
-                else:
-                    for g, sink in zip(pg_, sinks):
-                        if g is None:
-                            sink.zero_()
-                        else:
-                            torch.mul(g, sink_scale, out=sink)
-                self.param_grad_sinks = sinks
+            _DeferredWgrad.pending = [] if defer_wgrad else None
+            try:
+                grads = list(torch.autograd.grad(need, targets, [g for g in self.static_grad_outputs if g is not None],
+                                                 allow_unused=True))
+            finally:
+                stash, _DeferredWgrad.pending = (_DeferredWgrad.pending or []), None
+            if param_grad_sinks is not None and not stash:
+                write_sinks(grads[n_in:])
+        if stash:
+            index = {id(p): n_in + j for j, p in enumerate(self._params)}
+            self.bwd_graph2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.bwd_graph2, pool=self._pool, stream=self._stream, capture_error_mode="thread_local"), \
+                    torch.no_grad():  # X of a layer is an activation inside the forward's autograd graph
+                for w, gy, x, c in stash:
+                    gw = _DeferredWgrad.compute(gy, x, c)
+                    k = index[id(w)]
+                    grads[k] = gw if grads[k] is None else grads[k] + gw
+                if param_grad_sinks is not None:
+                    write_sinks(grads[n_in:])
+            self._wgrad_stash = stash  # dY / X of the first graph stay allocated: the second graph reads them
         it = iter(grads)
         self.static_grad_inputs = [next(it) if x.requires_grad else None for x in self.static_inputs]
         self.static_grad_inputs += list(it)  # parameter gradients, in self._params order

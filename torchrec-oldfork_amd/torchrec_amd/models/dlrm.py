@@ -54,6 +54,8 @@ _SORT_PLACEMENT = os.environ.get("TORCHREC_AMD_SORT_PLACEMENT", "lookup")
 # HIP-graph + flat-gradient mode: run forward and backward of a step by hand instead of through the autograd engine
 # (DLRMTrain._explicit_step); TORCHREC_AMD_EXPLICIT_STEP=0 keeps the autograd path.
 _EXPLICIT_STEP = os.environ.get("TORCHREC_AMD_EXPLICIT_STEP", "1") != "0"
+# flat mode: capture the head segment's weight-gradient GEMMs into a second backward graph (0: one graph as before)
+_DEFER_WGRAD = os.environ.get("TORCHREC_AMD_DEFER_WGRAD", "1") != "0"
 
 
 def _sort_hooks(ebc: nn.Module):
@@ -321,7 +323,9 @@ class DLRMTrain(nn.Module):
         ebc = getattr(ebc, "sharded", ebc)  # a train pipeline may have wrapped it
         if hasattr(ebc, "set_output_buffer"):
             ebc.set_output_buffer(g_head.static_input(1).detach())
-        g_head.capture_backward(param_grad_sinks=head_sinks, sink_scale=scale)
+        # flat mode: the head's weight gradients go into a second graph that the explicit step replays after it has
+        # started the embedding-gradient all-to-all (modules/mlp.py _DeferredWgrad)
+        g_head.capture_backward(param_grad_sinks=head_sinks, sink_scale=scale, defer_wgrad=flat_grads and _DEFER_WGRAD)
         # the head's gradient w.r.t. the bottom-MLP output doubles as the bottom segment's grad_output buffer
         g_dense.capture_backward([g_head.static_grad_inputs[0]], param_grad_sinks=dense_sinks, sink_scale=scale)
         object.__setattr__(self, "_graphs", (B, g_dense, g_head))  # not sub-modules: state_dict keys unchanged
@@ -439,10 +443,12 @@ class DLRMTrain(nn.Module):
             if not ones:
                 g_head.static_grad_outputs[0].fill_(1.0)
                 object.__setattr__(self, "_loss_grad_ready", True)
-            g_head.bwd_graph.replay()
+            g_head.bwd_graph.replay()  # ends with the gradient of the pooled embeddings
+            step.start_backward(g_head.static_grad_inputs[1].view(B, -1))  # pack + gradient all-to-all (+ replicated tables)
+            if getattr(g_head, "bwd_graph2", None) is not None:
+                g_head.bwd_graph2.replay()  # the head's weight gradients, while the all-to-all is in flight
             if g_head.after_backward is not None:
-                g_head.after_backward()
-            step.start_backward(g_head.static_grad_inputs[1].view(B, -1))
+                g_head.after_backward()  # all-reduce of the head's slice of the flat gradient
             g_dense.bwd_graph.replay()  # its grad_output buffer IS the head's gradient w.r.t. the bottom-MLP output
             if g_dense.after_backward is not None:
                 g_dense.after_backward()

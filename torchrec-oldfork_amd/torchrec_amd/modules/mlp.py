@@ -53,6 +53,23 @@ class _WgradOverlap:
                 and not torch.cuda.is_current_stream_capturing())
 
 
+class _DeferredWgrad:
+    """Weight gradients set aside while a backward is being CAPTURED (distributed/hip_graph.py capture_backward(defer_wgrad=
+    True)): the capture of the input-gradient chain ends first, and the weight-gradient GEMMs are captured into a second
+    graph that the owner replays AFTER it has started the embedding-gradient all-to-all — dW is needed by nobody until the
+    optimizer, the all-to-all by the embedding backward (models/dlrm.py explicit step).  `pending` is a list while such a
+    capture is running, else None; entries are (weight parameter, dY, X, split-K chunks)."""
+
+    pending: Optional[list] = None
+
+    @classmethod
+    def compute(cls, gy: torch.Tensor, x: torch.Tensor, c: int) -> torch.Tensor:
+        B = x.shape[0]
+        if c > 1 and B % c == 0:
+            return torch.bmm(gy.view(c, B // c, -1).transpose(1, 2), x.view(c, B // c, -1)).sum(dim=0)
+        return gy.t() @ x
+
+
 class _LinearSplitKWgrad(torch.autograd.Function):
     """y = x W^T + b with the weight gradient computed as a batched GEMM over batch chunks.
 
@@ -103,12 +120,14 @@ class _LinearSplitKWgrad(torch.autograd.Function):
         c = ctx.chunks
 
         def wgrad():
-            if c > 1 and B % c == 0:
-                return torch.bmm(gy.view(c, B // c, -1).transpose(1, 2), x.view(c, B // c, -1)).sum(dim=0)
-            return gy.t() @ x
+            return _DeferredWgrad.compute(gy, x, c)
 
         w = ctx.weight_param
-        if w is not None and ctx.needs_input_grad[1] and _WgradOverlap.active_for(gy):
+        if (w is not None and ctx.needs_input_grad[1] and _DeferredWgrad.pending is not None and gy.is_cuda
+                and torch.cuda.is_current_stream_capturing()):
+            _DeferredWgrad.pending.append((w, gy, x, c))  # captured later, into the segment's second backward graph
+            gw = None
+        elif w is not None and ctx.needs_input_grad[1] and _WgradOverlap.active_for(gy):
             side, cur = _WgradOverlap.stream, torch.cuda.current_stream()
             ready = torch.cuda.Event()
             ready.record(cur)  # dY (and the step's earlier work on this stream) is complete for the side stream
