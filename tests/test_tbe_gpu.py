@@ -625,3 +625,51 @@ def test_full_size_criteo_26_tables_properties(B):
         touched[uniq] = True
         keep = ~touched[probe_ids[t]]
         assert torch.equal(ws[t][probe_ids[t]][keep], probe_before[t][keep]), f"table {t}: an untouched row changed"
+
+
+@pytest.mark.parametrize("optname", ["EXACT_SGD", "EXACT_ROWWISE_ADAGRAD"])
+@pytest.mark.parametrize("case", [CASES[0], CASES[3], CASES[5]], ids=["0", "3", "5"])
+def test_lookup_without_autograd_is_the_autograd_path(case, optname):
+    """lookup_no_autograd / backward_no_autograd (what the explicit train step of models/dlrm.py drives) against the
+    module's own autograd path: same output, same weights and optimizer state after two steps, bit for bit — for the
+    fused module and for the dense-gradient module, into a caller's buffer too."""
+    def run(explicit, dense):
+        rng = np.random.default_rng(11)
+        if dense:
+            mod, _ = build_pair(case["rows"], case["dims"], case["ftm"], case["pooling"], None, rng, dense=True)
+        else:
+            mod, _ = build_pair(case["rows"], case["dims"], case["ftm"], case["pooling"], _opt(optname), rng, learning_rate=0.05)
+        outs, grads_w = [], []
+        for _ in range(2):
+            indices, offsets, psw = make_inputs(rng, case["rows"], case["B"], case["max_len"], case["ftm"],
+                                                case["fixed_len"], case["weighted"])
+            i, o, w = to_dev(indices), to_dev(offsets), to_dev(psw)
+            if explicit:
+                out, rec = mod.lookup_no_autograd(i, o, w)
+            else:
+                out = mod(i, o, w)
+            grad = to_dev(rng.standard_normal(tuple(out.shape)).astype(np.float32))
+            outs.append(out.detach().clone())
+            if explicit:
+                g = mod.backward_no_autograd(rec, grad)
+                if dense:
+                    grads_w.append(g.clone())
+            else:
+                if dense:
+                    mod.weights.grad = None
+                out.backward(grad)
+                if dense:
+                    grads_w.append(mod.weights.grad.clone())
+        torch.cuda.synchronize()
+        state = [] if dense else [tuple(s.clone() for s in st) for st in mod.split_optimizer_states()]
+        return outs, [w.clone() for w in mod.split_embedding_weights()], state, grads_w
+
+    for dense in (False, True):
+        if dense and optname != "EXACT_SGD":
+            continue
+        a, b = run(False, dense), run(True, dense)
+        for x, y in zip(a[0] + a[1] + a[3], b[0] + b[1] + b[3]):
+            assert torch.equal(x, y)
+        for sa, sb in zip(a[2], b[2]):
+            for x, y in zip(sa, sb):
+                assert torch.equal(x, y)
