@@ -236,11 +236,21 @@ def main(args):
         # wraps the dense modules (distributed/train_pipeline.py explains why)
         # With a process group the segments' gradients travel through ONE flat buffer that is all-reduced
         # per segment, instead of DDP's per-parameter bucket copies (models/dlrm.py)
+        failure = None
         try:
             train_model.capture_hip_graphs(B_local, flat_grads=True, process_group=env.process_group)
         except Exception as e:  # measured run must not die on a capture problem: run the segments eagerly
-            print(f"[bench] HIP-graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr, flush=True)
-            graphs_note = f"FELL BACK to eager: capture failed with {type(e).__name__}: {str(e)[:200]}"
+            failure = f"{type(e).__name__}: {str(e)[:200]}"
+            print(f"[bench] HIP-graph capture failed ({failure}); running eagerly", file=sys.stderr, flush=True)
+        if world > 1:
+            # every rank must take the same path (graphs reduce the dense gradients through the flat buffer, the eager
+            # fallback through DistributedDataParallel): one rank's failure is everybody's
+            ok = torch.tensor([0 if failure else 1], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0 and failure is None:
+                failure = "another rank's capture failed"
+        if failure is not None:
+            graphs_note = f"FELL BACK to eager: capture failed with {failure}"
             train_model._graphs = None
             if hasattr(train_model, "_flat_dense"):
                 object.__delattr__(train_model, "_flat_dense")
