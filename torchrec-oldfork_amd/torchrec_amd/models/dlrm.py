@@ -58,6 +58,10 @@ _EXPLICIT_STEP = os.environ.get("TORCHREC_AMD_EXPLICIT_STEP", "1") != "0"
 _DEFER_WGRAD = os.environ.get("TORCHREC_AMD_DEFER_WGRAD", "1") != "0"
 
 
+def _pad64(n: int) -> int:
+    return (n + 63) // 64 * 64
+
+
 def _sort_hooks(ebc: nn.Module):
     """(defer, launch) callables of a collection that lets its caller place the backward sort, or (None, None)."""
     if _SORT_PLACEMENT != "head":
@@ -259,18 +263,25 @@ class DLRMTrain(nn.Module):
         if flat_grads:
             # the parameters move into ONE flat buffer too (same order as the flat gradient: head, bottom MLP, the
             # rest), before anything captures their addresses: the dense optimizer becomes one kernel (optim/flat.py)
-            order = ([q for q in head.parameters() if q.requires_grad] + [q for q in m.dense_arch.parameters() if q.requires_grad])
-            seen = {id(q) for q in order}
-            order += [q for q in self.parameters() if q.requires_grad and id(q) not in seen]
-            if all(q.dtype == torch.float32 and q.device == dev for q in order):
-                flat_param = torch.empty(sum(q.numel() for q in order), dtype=torch.float32, device=dev)
-                off = 0
+            seg_head = [q for q in head.parameters() if q.requires_grad]
+            seg_dense = [q for q in m.dense_arch.parameters() if q.requires_grad]
+            seen = {id(q) for q in seg_head + seg_dense}
+            seg_rest = [q for q in self.parameters() if q.requires_grad and id(q) not in seen]
+            if all(q.dtype == torch.float32 and q.device == dev for q in seg_head + seg_dense + seg_rest):
+                # every segment starts on a 256-B boundary (the head ends with a 1-element bias: without the padding the
+                # bottom MLP's weights and the replicated tables would sit at addresses that are 4 mod 16)
+                starts, total = [], 0
+                for seg in (seg_head, seg_dense, seg_rest):
+                    starts.append(total)
+                    total = _pad64(total + sum(q.numel() for q in seg))
+                flat_param = torch.zeros(total, dtype=torch.float32, device=dev)
                 with torch.no_grad():
-                    for q in order:
-                        view = flat_param[off:off + q.numel()].view_as(q)
-                        view.copy_(q)
-                        q.data = view
-                        off += q.numel()
+                    for seg, off in zip((seg_head, seg_dense, seg_rest), starts):
+                        for q in seg:
+                            view = flat_param[off:off + q.numel()].view_as(q)
+                            view.copy_(q)
+                            q.data = view
+                            off += q.numel()
         g_dense = GraphedSegment(m.dense_arch, [torch.randn(B, dense_in, device=dev)])
         g_head = GraphedSegment(
             head, [g_dense.static_outputs[0].detach().requires_grad_(True),
@@ -288,9 +299,10 @@ class DLRMTrain(nn.Module):
             # every other trainable dense parameter of the model (the replicated tiny tables of a sharded
             # collection): its gradient arrives through autograd and joins the flat buffer after backward
             extras = [q for q in self.parameters() if q.requires_grad and id(q) not in graphed]
-            n_head = sum(q.numel() for q in g_head._params)
-            n_dense = sum(q.numel() for q in g_dense._params)
-            n_extra = sum(q.numel() for q in extras)
+            # same layout as the flat parameter buffer: [head | pad | bottom MLP | pad | rest | pad], segments 256-B aligned
+            n_head = _pad64(sum(q.numel() for q in g_head._params))
+            n_dense = _pad64(sum(q.numel() for q in g_dense._params))
+            n_extra = _pad64(sum(q.numel() for q in extras))
             flat = torch.zeros(n_head + n_dense + n_extra, dtype=torch.float32, device=dev)
 
             def views(params, off):
