@@ -42,8 +42,9 @@ def _train(hip_graphs: bool, steps: int = 6, flat: bool = False):
     model.train()
     it = iter(data)
     losses = [float(pipe.progress(it)[0].detach()) for _ in range(steps)]
-    # flat-gradient graph mode under the pipeline = the explicit (no autograd engine) step, also without an exchange
-    assert getattr(tm, "explicit_steps", 0) == (steps if flat else 0)
+    # graph mode under the pipeline (captured here in flat-gradient mode, or lazily by the pipeline) = the explicit
+    # (no autograd engine) step, also without an exchange
+    assert getattr(tm, "explicit_steps", 0) == (steps if (flat or hip_graphs) else 0)
     # one more step with ANOTHER batch size: graphed models must fall back to the eager segments (and, in
     # flat-gradient mode, still deliver the gradients through the flat buffer)
     small = RandomRecDataset(keys, B // 2, rows, manual_seed=9, num_generated_batches=1, num_batches=1, device=dev)

@@ -131,7 +131,9 @@ class TrainPipelineSparseDist:
             root = self._model.module if isinstance(self._model, DistributedModelParallel) else self._model
             if hasattr(root, "capture_hip_graphs"):
                 self._memcpy_stream.synchronize()
-                root.capture_hip_graphs(int(self._batch_i.dense_features.shape[0]))  # before any collective is in flight
+                # before any collective is in flight; flat-gradient mode, so that the step runs without the autograd
+                # engine (models/dlrm.py explicit step) — only un-wrapped (world-size-1) models get here
+                root.capture_hip_graphs(int(self._batch_i.dense_features.shape[0]), flat_grads=True)
         with torch.cuda.stream(self._data_dist_stream):
             self._data_dist_stream.wait_stream(self._memcpy_stream)
             self._start_data_dist(self._batch_i)
