@@ -76,7 +76,21 @@ typedef struct tbe_optimizer_args {
 } tbe_optimizer_args;
 
 const char* tbe_last_error(void);
-int32_t tbe_abi_version(void);
+int32_t tbe_abi_version(void); /* 3 */
+
+/* Faults that make RESULTS wrong without failing a call (everything here only enqueues kernels, so a kernel that
+ * gives up cannot fail the call that launched it).  Today there is one: a spin-wait of the pair sort (backward, row
+ * cache prefetch) that outlived its bound because a predecessor workgroup never published — the sorted order, and
+ * with it the row updates, are garbage then.  Kernels report into ONE line of GPU-mapped pinned host memory, so this
+ * call neither synchronises nor touches a stream: it returns what has arrived so far (everything from work whose
+ * completion the caller has observed).  Must stay 0; the Python host side raises on any increase at its check points
+ * (optimizer step, flush(), bounds_check_errors(), split_embedding_weights()) — the reference's counterpart of those
+ * points: torchrec/distributed/batched_embedding_kernel.py:250-257, 563.  On a box without a HIP device the word is
+ * plain host memory (nothing can write it but tbe_debug_inject_fault_host). */
+int tbe_fault_status(int64_t* sort_giveups);
+/* test hooks: the host-side / device-side write of one give-up without a sort that hangs */
+int tbe_debug_inject_fault_host(void);
+int tbe_debug_inject_sort_giveup(void* stream);
 
 /* Optional kernel timing for the measurement harness (bench.py `roofline`): when enabled the
  * library brackets its dominant kernels with HIP events recorded on the launch stream.
@@ -163,6 +177,9 @@ int tbe_forward_nobag_f32(const uint64_t* feat_weights, const int64_t* feat_rows
  *        (a multiple of 4) and that every table / state base, out offset and the gradient rows
  *        are 16-B aligned; enables the specialised kernels.  0 is always correct.
  * workspace: at least tbe_backward_workspace_bytes(N, F, B, max_D, key_bits) bytes.
+ * Limits: F*B < 2^32 and N < 2^29 ids per call (the pair sort counts in 29 bits); tbe_backward_workspace_bytes
+ *         returns 0 and the entry points TBE_ERR_INVALID_ARGUMENT beyond them, before anything is launched.
+ *         The same N < 2^29 holds for tbe_cache_prefetch and tbe_sort_pairs.
  * ---------------------------------------------------------------------------------- */
 size_t tbe_backward_workspace_bytes(int64_t N, int32_t F, int32_t B, int32_t max_D,
                                     int32_t key_bits);
@@ -196,8 +213,7 @@ int tbe_backward_prepare(const int64_t* feat_rows, const int64_t* feat_row_base,
  * Sorts n (key, payload) pairs on the low key_bits bits of the keys; equal keys keep input order.
  * key_bytes / payload_bytes: 4 or 8.  keys / payload are overwritten with the sorted result; keys_tmp /
  * payload_tmp are scratch of the same size.  workspace >= tbe_sort_pairs_workspace_bytes(n, key_bits).
- * tbe_debug_sort_timeouts: number of spin-wait give-ups inside the sort since the library was loaded
- * (must stay 0; synchronises the device). */
+ * tbe_debug_sort_timeouts: tbe_fault_status after a device synchronisation (tests). */
 size_t tbe_sort_pairs_workspace_bytes(int64_t n, int32_t key_bits);
 int tbe_sort_pairs(void* keys, void* keys_tmp, void* payload, void* payload_tmp, int64_t n,
                    int32_t key_bits, int32_t key_bytes, int32_t payload_bytes, void* workspace,

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/tbe_hip.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), "ctypes SIGNATURES out of sync with the header"
-    assert lib.tbe_abi_version() == 2
+    assert lib.tbe_abi_version() == 3
 
 
 def test_argument_validation_happens_before_any_launch():
@@ -32,6 +32,34 @@ def test_argument_validation_happens_before_any_launch():
     assert rc == -1 and b"n < 0" in lib.tbe_last_error()
     rc = lib.tbe_forward_pooled_f32(None, None, None, None, 0, 1, 0, None, 0, None, None, 0, None, None, 0, None, None, None)
     assert rc == -1
+
+
+def test_a_reported_kernel_fault_raises_once_at_the_next_check_point():
+    """A sort give-up is written to the library's fault word (GPU-mapped host memory; plain host memory on a box
+    without a device) and must surface as an exception at the host's next check point — a delta, so one raise per
+    batch of faults.  Here the host-side test hook plays the kernel."""
+    lib = _lib.load()
+    _lib.raise_on_faults("test: clean start")  # nothing pending
+    before = _lib.fault_count()
+    assert lib.tbe_debug_inject_fault_host() == 0
+    assert _lib.fault_count() == before + 1
+    with pytest.raises(_lib.KernelFaultError, match="give-up"):
+        _lib.raise_on_faults("test")
+    _lib.raise_on_faults("test: the same fault is not reported twice")
+    assert lib.tbe_debug_inject_fault_host() == 0 and lib.tbe_debug_inject_fault_host() == 0
+    with pytest.raises(_lib.KernelFaultError, match="2 spin-wait"):
+        _lib.raise_on_faults("test")
+
+
+def test_backward_and_prefetch_refuse_more_than_2_pow_29_ids_before_any_launch():
+    """the sort's {tag | count} words cap a call at 2^29 - 1 ids; every entry point says so up front."""
+    lib = _lib.load()
+    big = 1 << 29
+    assert lib.tbe_backward_workspace_bytes(big, 1, 1, 128, 20) == 0
+    assert lib.tbe_backward_workspace_bytes(big - 1, 1, 1, 128, 20) > 0
+    assert lib.tbe_cache_prefetch_workspace_bytes(big, 20) == 0
+    rc = lib.tbe_backward_prepare(None, None, 1, 1, 128, 20, None, big, None, 0, 0, None, 0, None, None, None)
+    assert rc == -1 and b"2^29" in lib.tbe_last_error()
 
 
 def test_cpu_tensors_are_refused_not_silently_computed():

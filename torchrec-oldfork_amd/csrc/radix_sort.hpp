@@ -44,6 +44,7 @@ constexpr int kMaxRadix = 1 << kMaxDigitBits;
 constexpr int kMaxPasses = 7;
 constexpr int kTagShift = 29;  // word = (pass + 1) << 29 | count ; count < 2^29
 constexpr uint32_t kCountMask = (1u << kTagShift) - 1u;
+constexpr int64_t kSortMaxPairs = 1ll << kTagShift;  // pairs per sort (the count field of a histogram word)
 constexpr int kSpinLimit = 1 << 20;  // polls per thread before it gives up (~1 s)
 
 // development aid: when set (tbe_debug_set_sort_stamps), every segment writes 8 wall-clock stamps (100 MHz) per pass
@@ -54,8 +55,15 @@ static uint64_t* g_sort_stamps = nullptr;
       a.stamps[(static_cast<size_t>(a.pass) * kSortMaxBlocks + b) * 8 + (i)] = wall_clock64();     \
   } while (0)
 
-// spin-wait give-ups (a predecessor never published): results are garbage then, but nothing hangs
-__device__ unsigned int g_sort_timeouts;
+// Spin-wait give-ups (a predecessor never published within kSpinLimit polls): nothing hangs, but the prefix sums — and
+// with them the sorted order — are garbage then.  Every give-up is written to the library's FAULT WORD (error.cpp: a
+// line of GPU-mapped host memory), which the host side reads without a sync (tbe_fault_status) and turns into an
+// exception at its next check point (fbgemm_gpu/_lib.py raise_on_faults): wrong results are never silent.
+uint32_t* fault_word_device();  // error.cpp
+__device__ __forceinline__ void report_sort_giveup(uint32_t* fault) {
+  __hip_atomic_store(&fault[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_fetch_add(&fault[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 struct RadixPlan {
   int passes;
@@ -238,6 +246,7 @@ struct RadixPassArgs {
   uint32_t* next_totals;   // [radix] digit totals of the next pass, accumulated by this one (or nullptr)
   uint32_t* ticket;        // this pass's ticket counter
   uint64_t* stamps;        // debug: [passes][kSortMaxBlocks][8] or nullptr
+  uint32_t* fault;         // the library's fault word (never nullptr)
 };
 
 template <typename KeyT, typename ValT, int ROUNDS>
@@ -385,7 +394,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_pass_kernel(const RadixPas
           if (r < count) {
             while (static_cast<uint32_t>(w[u]) >> kTagShift != epoch || static_cast<uint32_t>(w[u] >> 32) >> kTagShift != epoch) {
               if (++spins > kSpinLimit) {
-                if (spins == kSpinLimit + 1) atomicAdd(&g_sort_timeouts, 1u);
+                if (spins == kSpinLimit + 1) report_sort_giveup(a.fault);
                 break;
               }
               __builtin_amdgcn_s_sleep(2);
@@ -496,7 +505,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_pass_kernel(const RadixPas
     for (int i = tid; i < count; i += kSortThreads) {
       const KeyT key = stage_k[i];
       const uint32_t pos = s_goff[static_cast<unsigned>((key >> a.shift) & dmask)] + static_cast<uint32_t>(i);
-      if (pos < a.N) {  // always true unless a wait gave up (garbage prefix): never write out of bounds
+      if (pos < a.N) {  // always true unless a wait gave up (garbage prefix, reported): never write out of bounds
         a.keys_out[pos] = key;
         a.vals_out[pos] = stage_v[i];
       }
@@ -511,7 +520,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_pass_kernel(const RadixPas
 template <typename KeyT, typename ValT>
 inline int radix_sort_pairs(KeyT* k0, KeyT* k1, ValT* v0, ValT* v1, int64_t N, int key_bits, const RadixWorkspace& ws,
                             hipStream_t st, int flags = 0) {
-  if (N >= (1ll << kTagShift)) {
+  if (N >= kSortMaxPairs) {
     set_error("radix_sort_pairs: N must be < 2^29");
     return TBE_ERR_UNSUPPORTED;
   }
@@ -521,6 +530,11 @@ inline int radix_sort_pairs(KeyT* k0, KeyT* k1, ValT* v0, ValT* v1, int64_t N, i
     return TBE_ERR_UNSUPPORTED;
   }
   if (N <= 0) return pl.passes & 1;
+  uint32_t* const fault = fault_word_device();
+  if (fault == nullptr) {  // a give-up could not be reported: refuse to sort rather than risk a silent wrong order
+    set_error("radix_sort_pairs: the fault word (pinned host memory) could not be allocated");
+    return TBE_ERR_LAUNCH;
+  }
   const int radix = 1 << pl.bits;
   const RadixGeom g = radix_geom(N, sizeof(KeyT) + sizeof(ValT));
   const size_t state_words = radix_state_words(N, key_bits, sizeof(KeyT) + sizeof(ValT));
@@ -551,6 +565,7 @@ inline int radix_sort_pairs(KeyT* k0, KeyT* k1, ValT* v0, ValT* v1, int64_t N, i
     a.totals = ws.totals + static_cast<size_t>(radix) * p;
     a.ticket = ws.tickets + p;
     a.stamps = g_sort_stamps;
+    a.fault = fault;
     const dim3 grid(static_cast<unsigned>(g.blocks)), block(kSortThreads);
     bool launched = true;
 #define TBE_SORT_PASS(R)                                                                  \

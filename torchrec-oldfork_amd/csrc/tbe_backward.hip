@@ -800,6 +800,7 @@ extern "C" size_t tbe_backward_workspace_bytes(int64_t N, int32_t F, int32_t B, 
   (void)F;
   (void)B;
   if (N <= 0) return 256;
+  if (N >= kSortMaxPairs) return 0;  // not sortable in one call (the backward entry points say why)
   BwdWorkspace w;
   if (carve(nullptr, N, max_D, key_bits, &w) != TBE_OK) return 0;
   return w.total;
@@ -822,8 +823,10 @@ static int backward_entry(
   TBE_REQUIRE(key_bits >= 1 && key_bits <= 64, "tbe_backward_fused_f32: key_bits=%d", key_bits);
   TBE_REQUIRE(pooling_mode == TBE_POOL_SUM || pooling_mode == TBE_POOL_MEAN || pooling_mode == TBE_POOL_NONE,
               "tbe_backward_fused_f32: pooling_mode %d", pooling_mode);
-  TBE_REQUIRE(static_cast<int64_t>(F) * B < (1ll << 32) && N < (1ll << 32),
-              "tbe_backward_fused_f32: F*B and N must be < 2^32");
+  TBE_REQUIRE(static_cast<int64_t>(F) * B < (1ll << 32), "tbe_backward_fused_f32: F*B must be < 2^32");
+  // the pair sort's histogram words hold {pass tag | count} with a 29-bit count (radix_sort.hpp)
+  TBE_REQUIRE(N < kSortMaxPairs, "tbe_backward_fused_f32: N = %lld ids in one call; the limit is 2^29 - 1 (split the batch)",
+              static_cast<long long>(N));
   TBE_REQUIRE(grad_row_stride > 0, "tbe_backward_fused_f32: grad_row_stride <= 0");
   if (phase == (kPhasePrepare | kPhaseApply) && per_sample_weights != nullptr) flags |= TBE_FLAG_WEIGHTED;
   TBE_REQUIRE(per_sample_weights == nullptr || (flags & TBE_FLAG_WEIGHTED) != 0,
@@ -993,12 +996,20 @@ extern "C" int tbe_sort_pairs(void* keys, void* keys_tmp, void* payload, void* p
 
 extern "C" int tbe_debug_sort_timeouts(int64_t* count) {
   TBE_REQUIRE(count != nullptr, "tbe_debug_sort_timeouts: null pointer");
-  unsigned int v = 0;
-  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_sort_timeouts), sizeof(v)) != hipSuccess) {
-    set_error("tbe_debug_sort_timeouts: hipMemcpyFromSymbol failed");
+  if (hipDeviceSynchronize() != hipSuccess) {
+    set_error("tbe_debug_sort_timeouts: hipDeviceSynchronize failed");
     return TBE_ERR_LAUNCH;
   }
-  *count = v;
+  return tbe_fault_status(count);
+}
+
+// the device side of a give-up without a sort that hangs: what radix_pass_kernel does when a wait outlives kSpinLimit
+__global__ void inject_sort_giveup_kernel(uint32_t* fault) { report_sort_giveup(fault); }
+extern "C" int tbe_debug_inject_sort_giveup(void* stream) {
+  uint32_t* const fault = fault_word_device();
+  TBE_REQUIRE(fault != nullptr, "tbe_debug_inject_sort_giveup: no fault word (no HIP device?)");
+  hipLaunchKernelGGL(inject_sort_giveup_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), fault);
+  TBE_CHECK_LAUNCH("tbe_debug_inject_sort_giveup");
   return TBE_OK;
 }
 

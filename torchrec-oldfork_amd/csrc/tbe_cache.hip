@@ -340,6 +340,7 @@ using namespace tbe;
 
 extern "C" size_t tbe_cache_prefetch_workspace_bytes(int64_t N, int32_t key_bits) {
   if (N <= 0) return 256;
+  if (N >= kSortMaxPairs) return 0;  // not sortable in one call (tbe_cache_prefetch says why)
   PrefetchWorkspace w;
   carve_prefetch(nullptr, N, key_bits, &w);
   return w.total;
@@ -352,7 +353,9 @@ extern "C" int tbe_cache_prefetch(const tbe_cache_desc* desc, const int32_t* fea
   CacheDev c;
   int rc = to_dev(desc, &c);
   if (rc != TBE_OK) return rc;
-  TBE_REQUIRE(F > 0 && B >= 0 && N >= 0 && N < (1ll << 31), "tbe_cache_prefetch: bad sizes");
+  TBE_REQUIRE(F > 0 && B >= 0 && N >= 0, "tbe_cache_prefetch: bad sizes");
+  TBE_REQUIRE(N < kSortMaxPairs, "tbe_cache_prefetch: N = %lld ids in one call; the limit is 2^29 - 1 (the pair sort's count field)",
+              static_cast<long long>(N));
   TBE_REQUIRE(key_bits >= 1 && key_bits <= 62, "tbe_cache_prefetch: key_bits=%d", key_bits);
   TBE_REQUIRE(iteration >= 0, "tbe_cache_prefetch: iteration < 0");
   TBE_REQUIRE(c.staging_cap >= N, "tbe_cache_prefetch: staging_cap (%d) must be >= N (%lld)", c.staging_cap, (long long)N);

@@ -50,6 +50,9 @@ class CacheDesc(ctypes.Structure):
 SIGNATURES = {
     "tbe_last_error": (ctypes.c_char_p, []),
     "tbe_abi_version": (c_i32, []),
+    "tbe_fault_status": (ctypes.c_int, [ctypes.POINTER(c_i64)]),
+    "tbe_debug_inject_fault_host": (ctypes.c_int, []),
+    "tbe_debug_inject_sort_giveup": (ctypes.c_int, [c_void_p]),
     "tbe_profile_enable": (ctypes.c_int, [c_i32]),
     "tbe_profile_read": (ctypes.c_int, [c_i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]),
     "tbe_profile_read_rows": (ctypes.c_int, [ctypes.POINTER(c_i64)]),
@@ -173,6 +176,37 @@ def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = load().tbe_last_error()
         raise RuntimeError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+class KernelFaultError(RuntimeError):
+    """A kernel of this library gave up on something its result depends on (include/tbe_hip.h `tbe_fault_status`)."""
+
+
+_faults_seen = 0
+
+
+def fault_count() -> int:
+    """Sort give-ups reported so far in this process (no sync: what has arrived in the fault word)."""
+    n = c_i64(0)
+    check(load().tbe_fault_status(ctypes.byref(n)), "tbe_fault_status")
+    return int(n.value)
+
+
+def raise_on_faults(where: str) -> None:
+    """Raises KernelFaultError if a kernel reported a fault since the last check (a delta: one raise per batch of
+    faults).  Costs one ctypes call, no sync — cheap enough for every optimizer step.  Called from the points where the
+    reference talks to its TBE module outside forward / backward (set_learning_rate in step / zero_grad:
+    torchrec/distributed/batched_embedding_kernel.py:250-257; flush before state_dict: :563) and from
+    bounds_check_errors() / split_embedding_weights()."""
+    global _faults_seen
+    n = fault_count()
+    if n > _faults_seen:
+        new, _faults_seen = n - _faults_seen, n
+        raise KernelFaultError(
+            f"{where}: {new} spin-wait give-up(s) inside the embedding pair sort since the last check — a predecessor "
+            "workgroup did not publish its histogram in time (GPU shared with another process, a debugger or profiler "
+            "pause?).  The sorted order, and with it the row updates (or the row cache's state), of at least one "
+            "backward / prefetch since then are WRONG; restore the tables from a checkpoint.")
 
 
 def ptr(t: Optional[torch.Tensor]) -> Optional[int]:

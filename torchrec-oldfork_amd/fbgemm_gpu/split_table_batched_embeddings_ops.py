@@ -20,7 +20,7 @@ import torch
 from torch import nn
 
 from . import _lib
-from ._lib import CacheDesc, OptimizerArgs, check, ptr, require_gpu, stream_ptr, workspace
+from ._lib import CacheDesc, OptimizerArgs, check, ptr, raise_on_faults, require_gpu, stream_ptr, workspace
 from .split_embedding_configs import EmbOptimType as OptimType
 from .split_embedding_configs import SparseType
 
@@ -404,6 +404,7 @@ class _TBEBase(nn.Module):
         (written in place by batched_embedding_kernel.py:541-544 and embedding_lookup.py:70).
         With MANAGED_CACHING tables the HBM row cache is written back and emptied first, so the views
         are current and the caller may write them."""
+        raise_on_faults("split_embedding_weights")
         if self._cache is not None:
             self._cache.flush(invalidate=True)
         return [self._table_view(self._flat_weights, t) for t in range(self.T)]
@@ -517,8 +518,11 @@ class _TBEBase(nn.Module):
 
     def bounds_check_errors(self) -> int:
         """Number of out-of-range indices (and malformed bags) seen so far; they contribute zero rows.  Rows
-        that belong to another rank's shard (`set_row_windows`) are NOT errors.  Syncs."""
-        return int(self._errors().item())
+        that belong to another rank's shard (`set_row_windows`) are NOT errors.  Syncs — and, with everything enqueued so
+        far complete, raises KernelFaultError if a sort inside a backward / prefetch gave up (_lib.raise_on_faults)."""
+        n = int(self._errors().item())
+        raise_on_faults("bounds_check_errors")
+        return n
 
     def _enforce_bounds_check_mode(self) -> None:
         """BoundsCheckMode.FATAL: raise as soon as a lookup has seen a bad id (costs a host sync per call);
@@ -651,7 +655,8 @@ class _TBEBase(nn.Module):
         with torch.cuda.device(dev):
             nbytes = lib.tbe_backward_workspace_bytes(N, self.F, B, self.max_D, self.key_bits)
             if nbytes == 0:
-                check(-2, "tbe_backward_workspace_bytes")
+                raise RuntimeError(f"TBE backward: {N} ids in one call is beyond the limit of 2^29 - 1 (include/tbe_hip.h): "
+                                   "split the batch")
             ws = workspace(nbytes, dev)
             side = self._side_stream
             if side is None or side.device != dev:
@@ -712,7 +717,8 @@ class _TBEBase(nn.Module):
                 return
             nbytes = lib.tbe_backward_workspace_bytes(N, self.F, B, self.max_D, self.key_bits)
             if nbytes == 0:
-                check(-2, "tbe_backward_workspace_bytes")
+                raise RuntimeError(f"TBE backward: {N} ids in one call is beyond the limit of 2^29 - 1 (include/tbe_hip.h): "
+                                   "split the batch")
             ws = workspace(nbytes, dev)
             check(
                 lib.tbe_backward_fused_f32(ptr(lay.feat_weights), ptr(lay.feat_D),
@@ -972,11 +978,17 @@ class SplitTableBatchedEmbeddingBagsCodegen(_TBEBase):
 
     # optimizer surface ---------------------------------------------------------------------
     def set_learning_rate(self, lr: float) -> None:
+        """Called by the fused optimizer's step() / zero_grad() every train step (batched_embedding_kernel.py:250-257):
+        the one per-step host call of the module outside forward / backward, hence also where a fault reported by an
+        earlier step's kernels surfaces (no sync; _lib.raise_on_faults)."""
         self.optimizer_args.learning_rate = float(lr)
+        raise_on_faults("set_learning_rate")
 
     def flush(self) -> None:
         """Write-back of the HBM row cache of MANAGED_CACHING tables to their host tables
-        (batched_embedding_kernel.py:563, 664); the cache stays warm."""
+        (batched_embedding_kernel.py:563, 664); the cache stays warm.  Raises KernelFaultError if a kernel reported a
+        fault since the last check (what is about to be saved would be wrong)."""
+        raise_on_faults("flush")
         if self._cache is not None:
             self._cache.flush(invalidate=False)
 

@@ -130,10 +130,26 @@ class TrainPipelineSparseDist:
         if self._hip_graphs:
             root = self._model.module if isinstance(self._model, DistributedModelParallel) else self._model
             if hasattr(root, "capture_hip_graphs"):
-                self._memcpy_stream.synchronize()
-                # before any collective is in flight; flat-gradient mode, so that the step runs without the autograd
-                # engine (models/dlrm.py explicit step) — only un-wrapped (world-size-1) models get here
-                root.capture_hip_graphs(int(self._batch_i.dense_features.shape[0]), flat_grads=True)
+                B = int(self._batch_i.dense_features.shape[0])
+                have = getattr(root, "_graphs", None)
+                if have is not None and have[0] == B:
+                    # the owner captured already (the documented N > 1 flow: DistributedModelParallel(init_data_parallel=
+                    # False) -> capture_hip_graphs(B, flat_grads=True, process_group=pg) -> init_data_parallel()).  Capturing
+                    # again would replace the flat gradient state by a world-1 one — the dense all-reduce would silently
+                    # disappear and the replicas diverge — and strand a FlatSGD built on the old buffers.
+                    pass
+                else:
+                    env = self._model._env if isinstance(self._model, DistributedModelParallel) else None
+                    if env is not None and env.world_size > 1:
+                        raise RuntimeError(
+                            "TrainPipelineSparseDist(hip_graphs=True): the lazy capture is for world size 1.  With a process "
+                            "group capture BEFORE the data-parallel setup: DistributedModelParallel(init_data_parallel=False), "
+                            "model.module.capture_hip_graphs(batch, flat_grads=True, process_group=env.process_group), "
+                            "model.init_data_parallel() — bench.py does")
+                    self._memcpy_stream.synchronize()
+                    # before any collective is in flight; flat-gradient mode, so that the step runs without the autograd
+                    # engine (models/dlrm.py explicit step)
+                    root.capture_hip_graphs(B, flat_grads=True)
         with torch.cuda.stream(self._data_dist_stream):
             self._data_dist_stream.wait_stream(self._memcpy_stream)
             self._start_data_dist(self._batch_i)

@@ -341,11 +341,14 @@ class DLRMTrain(nn.Module):
         # the head's gradient w.r.t. the bottom-MLP output doubles as the bottom segment's grad_output buffer
         g_dense.capture_backward([g_head.static_grad_inputs[0]], param_grad_sinks=dense_sinks, sink_scale=scale)
         object.__setattr__(self, "_graphs", (B, g_dense, g_head))  # not sub-modules: state_dict keys unchanged
+        # the explicit step fills d(loss) = 1 into the NEW head segment's grad-output buffer (zeros after capture)
+        object.__setattr__(self, "_loss_grad_ready", False)
 
-    def dense_optimizer(self, params, lr: float) -> torch.optim.Optimizer:
+    def dense_optimizer(self, params, lr: float, momentum: float = 0.0, weight_decay: float = 0.0) -> torch.optim.Optimizer:
         """SGD for the dense parameters (what examples/dlrm/dlrm_main.py:536-540 builds with torch.optim.SGD): one
         kernel over the flat parameter / gradient buffers when capture_hip_graphs(flat_grads=True) has laid them out
-        (optim/flat.py), torch.optim.SGD otherwise.  Call it AFTER capture_hip_graphs."""
+        (optim/flat.py), torch.optim.SGD otherwise — same hyper-parameters, same arithmetic.  Call it AFTER
+        capture_hip_graphs (a later capture moves the parameters into NEW flat buffers)."""
         params = list(params)
         st = getattr(self, "_flat_dense", None)
         if (st is not None and st.get("flat_param") is not None and {id(q) for q in st["params"]} <= {id(q) for q in params}
@@ -353,8 +356,8 @@ class DLRMTrain(nn.Module):
             from ..optim.flat import FlatSGD
 
             return FlatSGD(params, lr, flat_param=st["flat_param"], flat_grad=st["flat"], covered=st["params"],
-                           grad_views=st["views"])
-        return torch.optim.SGD(params, lr=lr)
+                           grad_views=st["views"], momentum=momentum, weight_decay=weight_decay)
+        return torch.optim.SGD(params, lr=lr, momentum=momentum, weight_decay=weight_decay)
 
     def flat_grad_parameters(self) -> List[nn.Parameter]:
         """Parameters whose gradients travel through the flat buffer (kept out of DDP)."""
