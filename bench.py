@@ -27,11 +27,12 @@ import subprocess
 import sys
 import time
 
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # before the HIP runtime starts (RCCL needs dmabuf IPC here)
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "torchrec-oldfork_amd")  # fbgemm_gpu/ + torchrec_amd/ (importing them sets HSA_ENABLE_IPC_MODE_LEGACY=0
+#                                                   before HIP initialises: RCCL needs dmabuf IPC on this platform)
 
-HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured copy rate
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); the on-box copy rate is measured per run
+#                           (roofline.peak_measured_copy_GBs)
 MFMA_F32_PEAK_TFLOPS = 157.3  # fp32 matrix peak (MI355X_MICROARCH.md)
 XGMI_LINK_GBS = 153.0     # one xGMI link, one direction; 7 links per GPU
 D = 128
@@ -68,8 +69,15 @@ def parse():
     ap.add_argument("--row-cap", type=int, default=0, help="debug: cap rows per table")
     ap.add_argument("--zipf", type=float, default=0.0, help="Zipf alpha for ids (0 = uniform)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0)
-    ap.add_argument("--num-batches", type=int, default=16, help="distinct pre-generated batches")
+    ap.add_argument("--cpu-seconds", type=float, default=24.0,
+                    help="time budget of the CPU baseline (it runs >= 10 train iterations per batch size whatever this says)")
+    ap.add_argument("--num-batches", type=int, default=32, help="distinct pre-generated batches (SURVEY.md §8d: >= 32)")
+    ap.add_argument("--seed", type=int, default=0, help="dense-parameter and table initialisation (tables are initialised as a "
+                    "function of (seed, table, global row): any sharding starts from the same model)")
+    ap.add_argument("--data-ranks", type=int, default=0,
+                    help="draw the batches as this many ranks would (rank r seeds its generator with 1234 + r, as the reference's "
+                         "examples do) and give every real rank its contiguous share: --gpus 1 --data-ranks 2 trains on the "
+                         "global batches of a --gpus 2 run.  0 = the number of ranks")
     ap.add_argument("--row-wise", type=int, default=-1,
                     help="shard the N largest tables row-wise.  Default (-1): at N > 1 the pinned mixed plan of BASELINE "
                          "config 3 / SURVEY.md §8d (the 4 largest tables row-wise, the rest table-wise or replicated), "
@@ -154,12 +162,31 @@ def read_profile(lib, slot):
     return tot.value, n.value
 
 
+def measure_copy_GBs(torch, dev) -> float:
+    """On-box device copy rate: a 1-GiB device-to-device copy, bytes read + written over the best of 5 (the ceiling a
+    pure streaming kernel reaches here, shown next to the 8 TB/s spec peak: SURVEY.md §8d)."""
+    n = 1 << 28  # 2^28 fp32 = 1 GiB
+    src = torch.empty(n, dtype=torch.float32, device=dev).fill_(1.0)
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    best = float("inf")
+    for _ in range(5):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        dst.copy_(src)
+        b.record()
+        b.synchronize()
+        best = min(best, a.elapsed_time(b))
+    del src, dst
+    return 2 * n * 4 / (best * 1e-3) / 1e9
+
+
 def main(args):
+    if PKG not in sys.path:
+        sys.path.insert(0, PKG)
     import torch
     import torch.distributed as dist
 
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import _paths  # noqa: F401
     from fbgemm_gpu import _lib
     from torchrec_amd.datasets.random import CRITEO_1TB_ROWS, DEFAULT_CAT_NAMES, INT_FEATURE_COUNT, RandomRecDataset
     from torchrec_amd.distributed.embeddingbag import EmbeddingBagCollectionSharder
@@ -177,8 +204,16 @@ def main(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # TORCHREC_AMD_BENCH_BACKEND=gloo: rehearsal of an N-rank run on FEWER GPUs than ranks (ranks share devices round robin;
+    # RCCL refuses two ranks on one device).  Every rank runs the product path — HIP kernels, HIP graphs, explicit step,
+    # flat-gradient all-reduce; only the all-to-all is staged through the host (distributed/_rehearsal.py).  The line says
+    # so (`backend`, `rehearsal`); its timings are not multi-GPU timings.
+    backend = os.environ.get("TORCHREC_AMD_BENCH_BACKEND", "nccl")
+    if backend not in ("nccl", "gloo"):
+        raise SystemExit("TORCHREC_AMD_BENCH_BACKEND must be nccl or gloo")
+    dev_index = local_rank % max(torch.cuda.device_count(), 1) if backend == "gloo" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     # TORCHREC_AMD_FORCE_EXCHANGE=1: rehearsal of the N > 1 data path on one GPU (a one-rank RCCL group)
     # (TORCHREC_AMD_FORCE_DDP=1 additionally wraps the dense modules in DistributedDataParallel over that group)
     # TORCHREC_AMD_FORCE_DP=1 replicates the tiny tables as an N > 1 plan does.
@@ -190,6 +225,11 @@ def main(args):
         with native_stdout_to_stderr():
             if rehearse:
                 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            elif backend == "gloo":
+                from torchrec_amd.distributed._rehearsal import stage_all_to_all_through_host
+
+                dist.init_process_group("gloo")
+                stage_all_to_all_through_host()
             else:
                 dist.init_process_group("nccl", device_id=dev)
             dist.barrier()  # the communicator (and its banner) exists before stdout is handed back
@@ -198,12 +238,16 @@ def main(args):
         env = ShardingEnv.from_local(1, 0)
     if args.global_batch % world:
         raise SystemExit("global batch must divide evenly over the ranks")
+    data_ranks = args.data_ranks or world
+    if data_ranks % world or args.global_batch % data_ranks:
+        raise SystemExit("--data-ranks must be a multiple of the number of ranks and divide the global batch")
     tuned = False
     if args.tuned_gemms == "on" and os.environ.get("PYTORCH_TUNABLEOP_TUNING", "0") != "1":
         from torchrec_amd.tuning import enable_tuned_gemms
         tuned = enable_tuned_gemms()
     B_local = args.global_batch // world
     rows = [min(r, args.row_cap) if args.row_cap else r for r in CRITEO_1TB_ROWS]
+    torch.manual_seed(args.seed)  # dense parameters: the same on every rank (rank 0's are broadcast anyway)
 
     # ---- model: examples/dlrm/dlrm_main.py:498-540 ------------------------------------------------
     tables = [EmbeddingBagConfig(name=f"t_{n}", embedding_dim=D, num_embeddings=rows[i], feature_names=[n])
@@ -231,6 +275,8 @@ def main(args):
         sharders=[EmbeddingBagCollectionSharder(fused_params={"learning_rate": args.lr})],
         planner=EmbeddingShardingPlanner(Topology(env.world_size), num_row_wise=num_rw or None),
         init_data_parallel=False)
+    shard = model.sharded_modules()[0]
+    shard.reset_parameters_sharding_invariant(args.seed)
     if hip_graphs:
         # HIP-graph replay of the collective-free dense segments; captured before DistributedDataParallel
         # wraps the dense modules (distributed/train_pipeline.py explains why)
@@ -269,13 +315,15 @@ def main(args):
     kinds = [p.sharding_type for p in next(iter(plan.plan.values())).values()]
     n_rw, n_dp = kinds.count("row_wise"), kinds.count("data_parallel")
 
+    per = data_ranks // world
     data = RandomRecDataset(DEFAULT_CAT_NAMES, B_local, rows, ids_per_feature=1, num_dense=INT_FEATURE_COUNT,
-                            manual_seed=1234 + rank, num_generated_batches=args.num_batches, device=dev,
-                            zipf_alpha=args.zipf or None)
+                            manual_seeds=[1234 + rank * per + j for j in range(per)],
+                            num_generated_batches=args.num_batches, device=dev, zipf_alpha=args.zipf or None)
     it = iter(data)
     pipe = TrainPipelineSparseDist(model, optimizer, dev)
     model.train()
     lib = _lib.load()
+    copy_GBs = measure_copy_GBs(torch, dev) if rank == 0 else None
 
     def sync_all():
         if world > 1:
@@ -288,10 +336,20 @@ def main(args):
     lib.tbe_profile_enable(1)
     for s in range(4):
         read_profile(lib, s)
+    stamps = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        pipe.progress(it)
+    stamps[0].record()
+    loss_first = loss_last = None
+    for k in range(args.steps):
+        out = pipe.progress(it)
+        stamps[k + 1].record()
+        # the loss of the first and the last timed step (a 4-byte device copy each: under HIP graphs the loss lives in
+        # a static buffer the next replay overwrites); read after the timed region
+        if k == 0:
+            loss_first = out[0].detach().clone()
+        if k == args.steps - 1:
+            loss_last = out[0].detach().clone()
     sync_all()
     elapsed = time.perf_counter() - t0
     lib.tbe_profile_enable(0)
@@ -301,6 +359,51 @@ def main(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     value = args.global_batch * args.steps / elapsed
+    step_ms = sorted(stamps[k].elapsed_time(stamps[k + 1]) for k in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
+
+    # ---- did the timed region compute the right thing?  ("make wrong results loud") ----------------
+    # (1) no kernel gave up (sort spin-waits), no id was out of range; (2) the loss of the first / last timed step and
+    # a checksum of every parameter, which tests/test_bench_rehearsal_gpu.py compares with an eager, un-pipelined,
+    # graph-free replay of the same batches and with a run at another world size
+    if os.environ.get("TORCHREC_AMD_BENCH_INJECT_FAULT") == "1":  # test hook: what a sort give-up during the run leaves behind
+        lib.tbe_debug_inject_fault_host()
+    sort_giveups = _lib.fault_count()  # everything is complete (sync_all): the fault word is final
+    bounds_errors = 0
+    if sort_giveups == 0:
+        for m in (shard._emb_module, shard._dp_module):
+            if m is not None:
+                bounds_errors += m.bounds_check_errors()
+    losses = torch.stack([loss_first.float().reshape(()), loss_last.float().reshape(())]).to(torch.float64)
+    def sums(tensors):  # [sum, sum of |x|] in float64
+        acc = torch.zeros(2, dtype=torch.float64, device=dev)
+        for x in tensors:
+            x = x.detach()
+            acc[0] += torch.sum(x, dtype=torch.float64)
+            acc[1] += torch.sum(x.abs(), dtype=torch.float64) if x.numel() < (1 << 28) else sum(
+                torch.sum(c.abs(), dtype=torch.float64) for c in x.view(-1).split(1 << 28))
+        return acc
+
+    emb_sum = sums(w for _, (w, _) in shard.local_shards().items())
+    dp_sum = sums(w for _, w in shard.dp_tables().items())
+    dense_sum = sums(q for n, q in model.named_parameters() if "_dp_module" not in n)
+    replicas_identical = True
+    if world > 1:
+        dist.all_reduce(losses)  # mean over the global batch = mean of the ranks' local means
+        losses /= world
+        dist.all_reduce(emb_sum)  # every sharded row lives on exactly one rank
+        lo, hi = torch.cat([dense_sum, dp_sum]), torch.cat([dense_sum, dp_sum])
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        replicas_identical = bool(torch.equal(lo, hi))  # dense parameters + replicated tables: bit-identical replicas
+        bs = torch.tensor([bounds_errors, sort_giveups], dtype=torch.int64, device=dev)
+        dist.all_reduce(bs)
+        bounds_errors, sort_giveups = int(bs[0].item()), int(bs[1].item())
+    checks = {"sort_giveups": sort_giveups, "bounds_check_errors": bounds_errors,
+              "loss_first": float(losses[0].item()), "loss_last": float(losses[1].item()),
+              # sum and sum of |x| over every dense parameter / every row of every table (float64)
+              "param_checksum": {"dense": dense_sum.tolist(), "embedding": (emb_sum + dp_sum).tolist()},
+              "dense_replicas_identical": replicas_identical}
 
     # ---- roofline of the dominant embedding kernel (this rank's launches) ---------------------------
     # Units per launch on this rank: every TBE launch covers the GLOBAL batch for the features this
@@ -308,7 +411,6 @@ def main(args):
     # At N > 1 a rank runs TWO lookups per step (the fused one over the global batch for its sharded
     # features, the dense-gradient one over its LOCAL batch for the replicated tiny tables); the
     # profile slots hold both, so everything below is per STEP: summed launch time, summed bytes.
-    shard = model.sharded_modules()[0]
     kind = shard._table_kind  # -2 replicated, -1 row-wise, >= 0 owning rank
     feat_units = sum((1.0 / world) if kind[i] == -1 else (1.0 if kind[i] == rank else 0.0) for i in range(F))
     feat_units += sum(1.0 for i in range(F) if kind[i] == -2) / world  # local batch = 1/W of the global batch
@@ -340,12 +442,11 @@ def main(args):
     roofline = None
     if dom:
         # PMC traffic (FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction) measured by a separate rocprofv3
-        # --pmc run of the same kernels (profiles/r01_pmc_traffic.json); only valid for the N = 1 shape.
+        # --pmc run of the same kernels (profiles/r0N_pmc_traffic.json); only valid for the N = 1 shape.
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-        if not os.path.exists(pmc_path):
-            pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if world == 1 and args.global_batch == 65536 and not args.zipf and os.path.exists(pmc_path):
+        pmc_path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{n}_pmc_traffic.json") for n in (3, 2, 1))
+                         if os.path.exists(q)), "")
+        if world == 1 and args.global_batch == 65536 and not args.zipf and not args.row_cap and pmc_path:
             pmc = json.load(open(pmc_path))
             hit = [v for k, v in pmc.items() if dom.split("(")[0] in k]
             if hit:
@@ -355,6 +456,10 @@ def main(args):
                     "traffic_source": (f"profiles/{os.path.basename(pmc_path)}: separate rocprofv3 --pmc passes of the same "
                                        "kernels at this shape (FETCH_SIZE x 2 + WRITE_SIZE), not collected in this run"
                                        if traffic is not None else None),
+                    # the spec peak above is what `frac` is quoted against; this is what a 1-GiB device copy reaches on
+                    # THIS box (bytes read + written over the best of 5), measured before the timed region
+                    "peak_measured_copy_GBs": round(copy_GBs, 1) if copy_GBs else None,
+                    "frac_of_measured_copy": round(kern[dom]["GB/s"] / copy_GBs, 4) if copy_GBs else None,
                     "avg_launch_us": round(kern[dom]["avg_us"], 1),
                     "distinct_rows_per_sample": round(U_launch / args.global_batch, 2),
                     "bwd_MB_if_all_rows_distinct": round(bwd_bytes_all_distinct / 1e6, 1),
@@ -370,11 +475,12 @@ def main(args):
         cap_txt = f"tables capped at {r['row_cap']} rows (host RAM < 100 GB)" if r["row_cap"] else "full-size tables (84.85 GiB in host memory)"
         cpu = {"value": round(big["train_samples_per_s"], 1), "unit": "samples/s", "cores": r["cores"], "kind": "port",
                "fwd_only_value": round(big["fwd_samples_per_s"], 1),
+               "value_min_max": [round(x, 1) for x in big["train_samples_per_s_min_max"]],
                "batch_4096": {"value": round(small["train_samples_per_s"], 1),
                               "fwd_only_value": round(small["fwd_samples_per_s"], 1)},
                "sample": (f"reference EmbeddingBagCollection design (26 x nn.EmbeddingBag sum, sparse=True + SGD; "
-                          f"embedding part only, no MLPs), {cap_txt}, batch {args.global_batch}: "
-                          f"{big['train_iters']} train + {big['fwd_iters']} fwd iterations, batch 4096: "
+                          f"embedding part only, no MLPs), {cap_txt}, batch {args.global_batch}: median of "
+                          f"{big['train_iters']} train + {big['fwd_iters']} fwd iterations (after one warm-up each), batch 4096: "
                           f"{small['train_iters']} + {small['fwd_iters']}; tables built in {r['build_s']:.1f} s (untimed)")}
 
     # ---- whole-step fractions and the binding resource (model-based, per rank) ------------------------
@@ -402,21 +508,27 @@ def main(args):
                "xgmi_bytes_per_rank_per_step": int(xgmi_bytes_rank + 2 * ids_bytes_rank),
                "note": "time each resource would need at its peak rate for this rank's share of one step; the largest binds"}
 
+    bad = sort_giveups != 0 or bounds_errors != 0 or not replicas_identical
     if rank == 0:
         if roofline is not None:
             roofline["end_to_end"] = end_to_end
         out = {
             "metric": "samples/sec Criteo-1TB DLRM batch 65536", "value": round(value, 1), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            # per-step times from HIP events on the compute stream (rank 0), next to the wall-clock mean above
+            "median_ms_per_step": round(median_ms, 3), "min_max_ms_per_step": [round(step_ms[0], 3), round(step_ms[-1], 3)],
+            "higher_is_better": True, "scaling": "strong",
             # the reference's only published number is 5 497 159.68 samples/s on 8 x A100-40GB
             # (examples/dlrm/README.MD:45, real Criteo data, end to end) — comparable at N = 8 only
-            "vs_baseline": round(value / 5497159.68, 3) if world == 8 else None,
+            "vs_baseline": round(value / 5497159.68, 3) if world == 8 and backend == "nccl" else None,
             "dtype": "f32", "data": "synthetic", "hip_graphs": hip_graphs, "hip_graphs_note": graphs_note,
             "explicit_backward_steps": int(getattr(train_model, "explicit_steps", 0)),
             "tuned_gemms": tuned,
-            "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 0,
+            "rccl_ranks": dist.get_world_size() if dist.is_initialized() and dist.get_backend() == "nccl" else 0,
             "backend": dist.get_backend() if dist.is_initialized() else None,
+            "rehearsal": (f"{world} ranks on {torch.cuda.device_count()} GPU(s) over gloo, all-to-all staged through the host: "
+                          "NOT a multi-GPU timing" if world > 1 and backend == "gloo" else None),
             "launcher": os.environ.get("TORCHREC_AMD_BENCH_LAUNCHER", "external torchrun" if world > 1 else "direct"),
             "config": {"workload": "DLRM Criteo-1TB shape: 26 tables (177.9M rows, 84.85 GiB fp32, D=128), 13 dense, "
                                    "pooling factor 1, dense 512-256-128, over 1024-1024-512-256-1, fused exact SGD",
@@ -427,12 +539,19 @@ def main(args):
                                 "table_wise_per_rank": n_tw_per_rank, "row_wise_arg": args.row_wise,
                                 "source": ("pinned mixed plan (BASELINE config 3, SURVEY.md §8d)" if args.row_wise < 0 and world > 1
                                            else "torchrec_amd planner" if args.row_wise <= 0 else "--row-wise")},
-                       "ids": f"zipf({args.zipf})" if args.zipf else "uniform", "row_cap": args.row_cap or None},
-            "binding": binding, "roofline": roofline, "cpu_baseline": cpu,
+                       "ids": f"zipf({args.zipf})" if args.zipf else "uniform", "row_cap": args.row_cap or None,
+                       "distinct_batches": args.num_batches, "seed": args.seed, "data_ranks": data_ranks},
+            "checks": checks, "binding": binding, "roofline": roofline, "cpu_baseline": cpu,
         }
-        print(json.dumps(out), flush=True)
+        # a run whose kernels gave up, saw out-of-range ids or let the replicas drift measured the wrong computation:
+        # the line goes to stderr and the exit code says so
+        print(json.dumps(out), file=sys.stderr if bad else sys.stdout, flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
+    if bad:
+        print(f"[bench] INVALID RUN: sort give-ups {sort_giveups}, bounds-check errors {bounds_errors}, "
+              f"dense replicas identical: {replicas_identical}", file=sys.stderr, flush=True)
+        sys.exit(4)
 
 
 if __name__ == "__main__":

@@ -49,11 +49,15 @@ def default_row_cap() -> int:
 
 
 def time_cpu_baseline(rows: List[int], dim: int, batches=(4096, 65536), seconds_budget: float = 24.0,
-                      row_cap: Optional[int] = None, seed: int = 1234):
+                      row_cap: Optional[int] = None, seed: int = 1234, min_train_iters: int = 10, min_fwd_iters: int = 5):
     """Times forward and forward+backward+SGD of the reference design on the host cores with the same id
     distribution as the GPU run (uniform, pooling factor 1), at every batch size in `batches` (one model,
     built once).  `row_cap`: None = default_row_cap(), 0 = full tables.  Tables are filled with a constant
     (every page is written once, so lookups touch real memory; the values do not matter for timing).
+    Per batch size: one untimed forward and one untimed train iteration, then at least `min_fwd_iters` forwards and
+    `min_train_iters` train iterations (more while the time budget lasts), each timed on its own; the throughput
+    quoted is batch / MEDIAN iteration time (a mean over 4 iterations moved by 2x between boxes: VERDICT round 2),
+    the spread is reported next to it.
     Returns {"cores", "row_cap", "build_s", "per_batch": {batch: {...}}}."""
     g = torch.Generator()
     g.manual_seed(seed)
@@ -76,24 +80,37 @@ def time_cpu_baseline(rows: List[int], dim: int, batches=(4096, 65536), seconds_
     opt = torch.optim.SGD(ebc.parameters(), lr=0.01)
     per_batch = {}
     share = seconds_budget / max(len(batches), 1)
+
+    def median(xs):
+        xs = sorted(xs)
+        n = len(xs)
+        return xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2])
+
     for batch in batches:
         values = torch.cat([torch.randint(0, r, (batch,), generator=g) for r in capped])
         offsets = torch.arange(F * batch + 1)
-        ebc(values, offsets)  # warm-up
-        t0, n_f = time.perf_counter(), 0
-        with torch.no_grad():
-            while time.perf_counter() - t0 < share / 3 or n_f < 2:
-                ebc(values, offsets)
-                n_f += 1
-        fwd_s = (time.perf_counter() - t0) / n_f
         grad = torch.randn(batch, F * dim, generator=g)
-        t0, n_t = time.perf_counter(), 0
-        while time.perf_counter() - t0 < share * 2 / 3 or n_t < 2:
+
+        def train_iter():
             opt.zero_grad()
             ebc(values, offsets).backward(grad)
             opt.step()
-            n_t += 1
-        train_s = (time.perf_counter() - t0) / n_t
-        per_batch[batch] = {"fwd_samples_per_s": batch / fwd_s, "train_samples_per_s": batch / train_s,
-                            "fwd_iters": n_f, "train_iters": n_t}
+
+        with torch.no_grad():
+            ebc(values, offsets)  # warm-up
+        train_iter()  # warm-up
+        fwd_t, t_begin = [], time.perf_counter()
+        with torch.no_grad():
+            while len(fwd_t) < min_fwd_iters or time.perf_counter() - t_begin < share / 4:
+                t0 = time.perf_counter()
+                ebc(values, offsets)
+                fwd_t.append(time.perf_counter() - t0)
+        train_t, t_begin = [], time.perf_counter()
+        while len(train_t) < min_train_iters or time.perf_counter() - t_begin < share * 3 / 4:
+            t0 = time.perf_counter()
+            train_iter()
+            train_t.append(time.perf_counter() - t0)
+        per_batch[batch] = {"fwd_samples_per_s": batch / median(fwd_t), "train_samples_per_s": batch / median(train_t),
+                            "fwd_iters": len(fwd_t), "train_iters": len(train_t),
+                            "train_samples_per_s_min_max": [batch / max(train_t), batch / min(train_t)]}
     return {"cores": torch.get_num_threads(), "row_cap": row_cap, "build_s": build_s, "per_batch": per_batch}

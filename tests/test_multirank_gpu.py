@@ -397,7 +397,10 @@ def _e2e_model(env, dev, dp_max_rows, graph_batch=0, flat=False, seed=0):
         tm.capture_hip_graphs(graph_batch, flat_grads=flat, process_group=env.process_group)
         model.init_data_parallel()
     opt = CombinedOptimizer([model.fused_optimizer,
-                             KeyedOptimizerWrapper(dict(model.named_parameters()), lambda p: torch.optim.SGD(p, lr=E_LR))])
+                             # flat mode: the one-kernel SGD over the flat buffers, as bench.py builds it (optim/flat.py)
+                             KeyedOptimizerWrapper(dict(model.named_parameters()),
+                                                   (lambda p: tm.dense_optimizer(p, lr=E_LR)) if (graph_batch and flat)
+                                                   else (lambda p: torch.optim.SGD(p, lr=E_LR)))])
     return keys, model, opt
 
 
@@ -455,7 +458,12 @@ def _e2e_worker(rank, W, port, ret, hip_graphs=False):
         if hip_graphs == "flat":
             assert len(model.module.flat_grad_parameters()) > 0
         _e2e_init_tables(model)
-        ret[rank] = _e2e_run(model, opt, keys, _e2e_batches(W), rank, W, dev, False)
+        # "flat": the pipeline is ALSO asked for HIP graphs: its lazy capture must recognise the owner's
+        # capture and leave it alone — re-capturing would swap in a world-1 flat-gradient state (no dense all-reduce,
+        # replicas diverge: the d0 == d1 check of the test would fail) and strand the optimizer's flat buffers
+        flat_state = getattr(model.module, "_flat_dense", None)
+        ret[rank] = _e2e_run(model, opt, keys, _e2e_batches(W), rank, W, dev, hip_graphs == "flat")
+        assert getattr(model.module, "_flat_dense", None) is flat_state
         assert (model.module._graphs is not None) == bool(hip_graphs)
         # flat-gradient graph mode runs forward AND backward by hand (DLRMTrain._explicit_step), no autograd engine
         assert (getattr(model.module, "explicit_steps", 0) == E_STEPS) == (hip_graphs == "flat")

@@ -264,13 +264,21 @@ def _e2e_worker(rank, W, port, ret):
         model.train()
         it = iter(data)
         losses = []
-        for _ in range(4):
+        for _ in range(3):
             loss = pipe.progress(it)[0]
             losses.append(float(loss))
+        # the 4th step under a torch profiler: the reference's range labels must show up (and only then: without a
+        # profiler `label()` hands out a shared no-op context, torchrec_amd/profiling.py)
+        from torchrec_amd import profiling
+        assert profiling.label("## forward ##") is profiling.label("## backward ##")  # no profiler: the no-op singleton
+        with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU]) as prof:
+            loss = pipe.progress(it)[0]
+        losses.append(float(loss))
+        seen_labels = sorted({e.key for e in prof.key_averages() if e.key.startswith("## ")})
         dense_sd = {k: v.detach().clone() for k, v in model.named_parameters()}
         shards = {n: (w.clone().numpy(), r0) for n, (w, r0) in model.sharded_modules()[0].local_shards().items()}
         assert set(model.sharded_modules()[0].dp_tables()) == {"t1", "t4"}  # 9 and 8 rows: replicated
-        ret[rank] = (losses, {k: v.numpy() for k, v in dense_sd.items()}, shards)
+        ret[rank] = (losses, {k: v.numpy() for k, v in dense_sd.items()}, shards, seen_labels)
     finally:
         dist.destroy_process_group()
 
@@ -280,9 +288,14 @@ def test_dlrm_e2e_dmp_ddp_pipeline_world2():
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_e2e_worker, args=(W, _free_port(), ret), nprocs=W, join=True)
-    l0, d0, s0 = ret[0]
-    l1, d1, s1 = ret[1]
+    l0, d0, s0, labels0 = ret[0]
+    l1, d1, s1, _ = ret[1]
     assert all(np.isfinite(l0)) and all(np.isfinite(l1))
+    # pipeline stages + exchange req / wait pairs, under the reference's label strings (train_pipeline.py:504-550,
+    # dist_data.py:190, comm_ops.py:489, 591)
+    for want in ("## zero_grad ##", "## forward ##", "## backward ##", "## optimizer ##", "## all2all_data:indices ##",
+                 "## alltoall_fwd_single ##", "## alltoall_bwd_single ##", "## tbe_lookup ##"):
+        assert want in labels0, (want, labels0)
     # DDP keeps the dense replicas identical
     for k in d0:
         np.testing.assert_allclose(d0[k], d1[k], rtol=0, atol=0)

@@ -39,20 +39,42 @@ class Batch:
 
 
 class RandomRecDataset:
-    """Iterable of `Batch`; generation happens on `device` with a seeded generator."""
+    """Iterable of `Batch`; generation happens on `device` with a seeded generator.
+
+    `manual_seeds` (instead of `manual_seed`): the batch is the concatenation, along the batch dimension, of
+    len(manual_seeds) sub-batches of batch_size / len(manual_seeds) samples, sub-batch j drawn exactly as a dataset with
+    manual_seed = manual_seeds[j] and that smaller batch size draws it.  One rank then sees the GLOBAL batches of a
+    multi-rank run (rank r of the reference's examples seeds with `seed + r`): how a world-size-1 run is compared
+    with a world-size-N run on the same samples (bench.py --data-ranks, tests/test_bench_rehearsal_gpu.py)."""
 
     def __init__(self, keys: List[str], batch_size: int, hash_sizes: List[int], ids_per_feature: int = 1,
                  num_dense: int = INT_FEATURE_COUNT, manual_seed: Optional[int] = None,
                  num_generated_batches: int = 32, num_batches: Optional[int] = None,
-                 device: Optional[torch.device] = None, zipf_alpha: Optional[float] = None) -> None:
+                 device: Optional[torch.device] = None, zipf_alpha: Optional[float] = None,
+                 manual_seeds: Optional[List[int]] = None) -> None:
         self.keys, self.batch_size, self.hash_sizes = keys, batch_size, hash_sizes
         self.ids_per_feature, self.num_dense, self.num_batches = ids_per_feature, num_dense, num_batches
         self.device = device or torch.device("cpu")
+        self.zipf_alpha = zipf_alpha
+        if manual_seeds is not None and len(manual_seeds) > 1:
+            if manual_seed is not None or batch_size % len(manual_seeds):
+                raise ValueError("manual_seeds: give either one seed or a list whose length divides the batch size")
+            subs = [RandomRecDataset(keys, batch_size // len(manual_seeds), hash_sizes, ids_per_feature, num_dense, sd,
+                                     num_generated_batches, None, self.device, zipf_alpha) for sd in manual_seeds]
+            self._pool = [self._concat([s._pool[i] for s in subs]) for i in range(num_generated_batches)]
+            return
+        if manual_seeds:
+            manual_seed = manual_seeds[0]
         self.gen = torch.Generator(device=self.device)
         if manual_seed is not None:
             self.gen.manual_seed(manual_seed)
-        self.zipf_alpha = zipf_alpha
         self._pool = [self._generate() for _ in range(num_generated_batches)]
+
+    def _concat(self, parts: List[Batch]) -> Batch:
+        F, L = len(self.keys), self.ids_per_feature
+        vals = torch.cat([p.sparse_features.values().view(F, -1) for p in parts], dim=1).reshape(-1)  # feature-major
+        kjt = KeyedJaggedTensor.from_fixed_lengths(self.keys, vals, [L] * F)
+        return Batch(torch.cat([p.dense_features for p in parts]), kjt, torch.cat([p.labels for p in parts]))
 
     def _ids(self, high: int, n: int) -> torch.Tensor:
         if self.zipf_alpha is None:

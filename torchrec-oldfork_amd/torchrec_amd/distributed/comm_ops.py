@@ -14,6 +14,7 @@ import torch
 import torch.distributed as dist
 from torch import Tensor
 
+from ..profiling import label
 from . import _device_ops  # noqa: F401
 from . import embeddingbag as _eb
 from .types import Awaitable, NoWait
@@ -48,8 +49,9 @@ class _A2APooledReq(torch.autograd.Function):
         st["send_splits"] = [b * D_local for b in st["B_per_rank"]]
         st["recv_splits"] = [B_me * d for d in st["dims"]]
         st["recv"] = torch.empty(sum(st["recv_splits"]), dtype=x.dtype, device=x.device)
-        st["work"] = dist.all_to_all_single(st["recv"], x.contiguous().view(-1), st["recv_splits"], st["send_splits"],
-                                            group=st["pg"], async_op=True)
+        with label("## alltoall_fwd_single ##"):  # comm_ops.py:489
+            st["work"] = dist.all_to_all_single(st["recv"], x.contiguous().view(-1), st["recv_splits"], st["send_splits"],
+                                                group=st["pg"], async_op=True)
         return st["recv"]
 
     @staticmethod
@@ -77,8 +79,9 @@ class _A2APooledWait(torch.autograd.Function):
         scale = 1.0 / W if _eb.GRADIENT_DIVISION else 1.0  # comm_ops.py:527-528
         send = torch.ops.tbe_hip.a2a_pooled_pack(grad_out, st["dims_t"], st["vec"], scale)
         st["grecv"] = torch.empty(sum(st["send_splits"]), dtype=grad_out.dtype, device=grad_out.device)
-        st["bwork"] = dist.all_to_all_single(st["grecv"], send, st["send_splits"], st["recv_splits"], group=st["pg"],
-                                             async_op=True)
+        with label("## alltoall_bwd_single ##"):  # comm_ops.py:591
+            st["bwork"] = dist.all_to_all_single(st["grecv"], send, st["send_splits"], st["recv_splits"], group=st["pg"],
+                                                 async_op=True)
         st["keep"] = send
         return st["recv"].new_zeros(1).expand(st["recv"].shape), None
 
@@ -113,8 +116,9 @@ class _RSReq(torch.autograd.Function):
         send = torch.cat([t.contiguous().view(-1) for t in inputs])
         n_me = inputs[me].numel()
         st["recv"] = torch.empty(W * n_me, dtype=send.dtype, device=send.device)
-        st["work"] = dist.all_to_all_single(st["recv"], send, [n_me] * W, [t.numel() for t in inputs], group=pg,
-                                            async_op=True)
+        with label("## reduce_scatter ##"):  # comm_ops.py:865
+            st["work"] = dist.all_to_all_single(st["recv"], send, [n_me] * W, [t.numel() for t in inputs], group=pg,
+                                                async_op=True)
         return st["recv"]
 
     @staticmethod
@@ -162,7 +166,8 @@ class _RSWait(torch.autograd.Function):
                 n *= d
             recv_splits.append(n)
         st["grecv"] = torch.empty(sum(recv_splits), dtype=g.dtype, device=g.device)
-        st["bwork"] = dist.all_to_all_single(st["grecv"], send, recv_splits, [g.numel()] * W, group=pg, async_op=True)
+        with label("## reduce_scatter_bw (all_gather) ##"):  # comm_ops.py:921
+            st["bwork"] = dist.all_to_all_single(st["grecv"], send, recv_splits, [g.numel()] * W, group=pg, async_op=True)
         st["keep"] = send
         return st["recv"].new_zeros(1).expand(st["recv"].shape), None
 

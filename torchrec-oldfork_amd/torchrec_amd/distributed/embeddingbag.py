@@ -38,6 +38,7 @@ from torch import nn
 
 from ..modules.embedding_configs import EmbeddingBagConfig, pooling_type_to_pooling_mode
 from ..modules.embedding_modules import EmbeddingBagCollection
+from ..profiling import label
 from ..sparse.jagged_tensor import KeyedJaggedTensor, KeyedTensor
 from . import _device_ops  # noqa: F401  (registers torch.ops.tbe_hip.*)
 from .planner import rw_block_size, rw_shard_rows
@@ -201,11 +202,13 @@ class _ExchangeState:
     def start_forward(self, emb: torch.Tensor) -> None:
         o, lay = self.o, self.lay
         self.recv_fwd = torch.empty(lay["recv_numel"], dtype=torch.float32, device=emb.device)
-        self.work = dist.all_to_all_single(self.recv_fwd, emb.reshape(-1), output_split_sizes=lay["recv_splits"],
-                                           input_split_sizes=lay["send_splits"], group=o._pg, async_op=True)
+        with label("## alltoall_fwd_single ##"):  # comm_ops.py:489
+            self.work = dist.all_to_all_single(self.recv_fwd, emb.reshape(-1), output_split_sizes=lay["recv_splits"],
+                                               input_split_sizes=lay["send_splits"], group=o._pg, async_op=True)
 
     def finish_forward(self) -> torch.Tensor:
-        self.work.wait()
+        with label("## alltoall_fwd_wait ##"):
+            self.work.wait()
         self.work = None
         lay = self.lay
         buf = self.o._output_buffer
@@ -229,12 +232,14 @@ class _ExchangeState:
             grad_out, lay["feat_out_col"], lay["feat_src"], lay["feat_slab_col"], lay["slab_offset"],
             lay["slab_stride"], lay["recv_numel"], o._vec_ok, scale)
         self.grad_recv = torch.empty(lay["send_numel"], dtype=torch.float32, device=grad_out.device)
-        self.bwd_work = dist.all_to_all_single(self.grad_recv, send, output_split_sizes=lay["send_splits"],
-                                               input_split_sizes=lay["recv_splits"], group=o._pg, async_op=True)
+        with label("## alltoall_bwd_single ##"):  # comm_ops.py:591
+            self.bwd_work = dist.all_to_all_single(self.grad_recv, send, output_split_sizes=lay["send_splits"],
+                                                   input_split_sizes=lay["recv_splits"], group=o._pg, async_op=True)
         self._send_keepalive = send
 
     def finish_backward(self) -> torch.Tensor:
-        self.bwd_work.wait()
+        with label("## alltoall_bwd_wait ##"):
+            self.bwd_work.wait()
         self.bwd_work = None
         self._send_keepalive = None
         return self.grad_recv.view(self.o._world_size * self.B, self.o._D_local)
@@ -501,6 +506,31 @@ class ShardedEmbeddingBagCollection(nn.Module):
             if w.numel():
                 w.uniform_(lt.cfg.get_weight_init_min(), lt.cfg.get_weight_init_max())
 
+    def reset_parameters_sharding_invariant(self, seed: int = 0, chunk_rows: int = 1 << 16) -> None:
+        """U(-sqrt(1/N), sqrt(1/N)) per table like _init_parameters, but as a function of (seed, table, global row)
+        only: every table is drawn in chunks of `chunk_rows` global rows, chunk c of table t from its own generator
+        seeded with (seed, t, c), and a shard copies the rows it holds.  Any sharding of the collection — and the
+        unsharded one — then starts from the same tables, which is what lets a world-size-N run be compared with a
+        world-size-1 run (the reference's tests copy a global model's state_dict into the shards instead:
+        test_model_parallel_base.py:92-122)."""
+        gen = torch.Generator(device=self._device)
+        index = {c.name: t for t, c in enumerate(self._embedding_bag_configs)}
+        targets = [(n, w, r0) for n, (w, r0) in self.local_shards().items()] + [(n, w, 0) for n, w in self.dp_tables().items()]
+        with torch.no_grad():
+            for name, w, row0 in targets:
+                cfg = self._embedding_bag_configs[index[name]]
+                lo, hi = cfg.get_weight_init_min(), cfg.get_weight_init_max()
+                n, D = w.shape
+                c = row0 // chunk_rows
+                while c * chunk_rows < row0 + n:
+                    g0 = c * chunk_rows
+                    rows = min(chunk_rows, cfg.num_embeddings - g0)
+                    gen.manual_seed((int(seed) * 1000003 + index[name]) * 1000003 + c)
+                    block = torch.rand((rows, D), generator=gen, device=self._device, dtype=torch.float32)
+                    a, b = max(g0, row0), min(g0 + rows, row0 + n)
+                    w[a - row0:b - row0].copy_(block[a - g0:b - g0].mul_(hi - lo).add_(lo))
+                    c += 1
+
     @property
     def fused_optimizer(self) -> Optional[EmbeddingFusedOptimizer]:
         return self._optim
@@ -679,11 +709,14 @@ class ShardedEmbeddingBagCollection(nn.Module):
             out_splits = [self._F_local * B * L] * W
             if self._exchange:
                 recv_v = torch.empty(sum(out_splits), dtype=send_v.dtype, device=send_v.device)
-                wk = dist.all_to_all_single(recv_v, send_v.view(-1), out_splits, in_splits, group=self._pg, async_op=True)
+                with label("## all2all_data:indices ##"):  # dist_data.py:190
+                    wk = dist.all_to_all_single(recv_v, send_v.view(-1), out_splits, in_splits, group=self._pg, async_op=True)
                 recv_w, wk2 = None, None
                 if send_w is not None:
                     recv_w = torch.empty(sum(out_splits), dtype=send_w.dtype, device=send_w.device)
-                    wk2 = dist.all_to_all_single(recv_w, send_w.view(-1), out_splits, in_splits, group=self._pg, async_op=True)
+                    with label("## all2all_data:weights ##"):  # dist_data.py:213
+                        wk2 = dist.all_to_all_single(recv_w, send_w.view(-1), out_splits, in_splits, group=self._pg,
+                                                     async_op=True)
             else:
                 recv_v, recv_w, wk, wk2 = send_v.reshape(-1), (send_w.reshape(-1) if send_w is not None else None), None, None
 
@@ -714,14 +747,18 @@ class ShardedEmbeddingBagCollection(nn.Module):
             k += n
         if self._exchange:
             recv_l = torch.empty(sum(len_out), dtype=lengths.dtype, device=lengths.device)
-            dist.all_to_all_single(recv_l, lengths, len_out, len_in, group=self._pg)
-            val_out = recv_l.view(W, -1).sum(dim=1).cpu().tolist()  # host sync (dist_data.py:396-398)
+            with label("## all2all_data:lengths ##"):  # dist_data.py:366
+                dist.all_to_all_single(recv_l, lengths, len_out, len_in, group=self._pg)
+            with label("## all2all_data:split length for a2a ##"):  # dist_data.py:388
+                val_out = recv_l.view(W, -1).sum(dim=1).cpu().tolist()  # host sync (dist_data.py:396-398)
             recv_v = torch.empty(sum(val_out), dtype=sent.values().dtype, device=lengths.device)
-            wk = dist.all_to_all_single(recv_v, sent.values(), val_out, val_in, group=self._pg, async_op=True)
+            with label("## all2all_data:indices ##"):
+                wk = dist.all_to_all_single(recv_v, sent.values(), val_out, val_in, group=self._pg, async_op=True)
             recv_w, wk2 = None, None
             if weights is not None:
                 recv_w = torch.empty(sum(val_out), dtype=weights.dtype, device=lengths.device)
-                wk2 = dist.all_to_all_single(recv_w, sent.weights(), val_out, val_in, group=self._pg, async_op=True)
+                with label("## all2all_data:weights ##"):
+                    wk2 = dist.all_to_all_single(recv_w, sent.weights(), val_out, val_in, group=self._pg, async_op=True)
         else:
             recv_l, recv_v, recv_w, wk, wk2 = lengths, sent.values(), sent.weights_or_none() if weights is not None else None, None, None
 
@@ -759,7 +796,8 @@ class ShardedEmbeddingBagCollection(nn.Module):
                                                     dist_input.offsets, dist_input.weights)
             return NoWait(KeyedTensor(keys, lpe, self._dp_fill(out, dist_input)))
         if self._emb_module is not None:
-            emb = self._emb_module(dist_input.values, dist_input.offsets, dist_input.weights)
+            with label("## tbe_lookup ##"):
+                emb = self._emb_module(dist_input.values, dist_input.offsets, dist_input.weights)
         else:
             emb = torch.zeros((self._world_size * B, 0), dtype=torch.float32, device=self._device,
                               requires_grad=True)
@@ -800,14 +838,17 @@ class ExplicitLookupStep:
         self.state: Optional[_ExchangeState] = None
         self._grad: Optional[torch.Tensor] = None
         if owner._exchange:
-            emb, self.rec = owner._emb_module.lookup_no_autograd(dist_input.values, dist_input.offsets, dist_input.weights)
+            with label("## tbe_lookup ##"):
+                emb, self.rec = owner._emb_module.lookup_no_autograd(dist_input.values, dist_input.offsets, dist_input.weights)
             self.state = _ExchangeState(owner, dist_input.batch_size)
             self.state.start_forward(emb)
             self._out = None
         else:
             out = owner._alias_output_buffer(dist_input.batch_size)
-            self._out, self.rec = owner._emb_module.lookup_no_autograd(
-                dist_input.values, dist_input.offsets, dist_input.weights, into=(out, owner._sharded_out_off, owner._D_total))
+            with label("## tbe_lookup ##"):
+                self._out, self.rec = owner._emb_module.lookup_no_autograd(
+                    dist_input.values, dist_input.offsets, dist_input.weights,
+                    into=(out, owner._sharded_out_off, owner._D_total))
 
     def finish(self) -> torch.Tensor:
         """[B_local, sum D] pooled embeddings in the collection's key order, inside the output buffer."""
@@ -838,7 +879,8 @@ class ExplicitLookupStep:
     def finish_backward(self) -> None:
         grad = self.state.finish_backward() if self.state is not None else self._grad
         self._grad = None
-        self.o._emb_module.backward_no_autograd(self.rec, grad)
+        with label("## tbe_backward_fused_optimizer ##"):
+            self.o._emb_module.backward_no_autograd(self.rec, grad)
 
 
 class EmbeddingBagCollectionSharder:

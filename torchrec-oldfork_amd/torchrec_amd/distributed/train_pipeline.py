@@ -11,6 +11,7 @@ from typing import Any, Iterator, List, Optional, Tuple
 
 import torch
 
+from ..profiling import label
 from .model_parallel import DistributedModelParallel
 
 
@@ -29,9 +30,10 @@ class _PipelinedEBC(torch.nn.Module):
         if req is None:
             return self.sharded.input_dist(features).wait()
         cur = torch.cuda.current_stream()
-        with torch.cuda.stream(self.pipeline._data_dist_stream):
-            dist_in = req.wait()
-        cur.wait_stream(self.pipeline._data_dist_stream)
+        with label("## wait_sparse_data_dist ##"):  # train_pipeline.py:213
+            with torch.cuda.stream(self.pipeline._data_dist_stream):
+                dist_in = req.wait()
+            cur.wait_stream(self.pipeline._data_dist_stream)
         dist_in.record_stream(cur)
         return dist_in
 
@@ -161,9 +163,11 @@ class TrainPipelineSparseDist:
         if self._batch_i is None:
             raise StopIteration
         if self._memcpy_stream is not None:
-            with torch.cuda.stream(self._memcpy_stream):
-                self._batch_ip2 = self._to_device(next(dataloader_iter, None), True)
-            torch.cuda.current_stream().wait_stream(self._data_dist_stream)
+            with label("## copy_batch_to_gpu ##"):  # train_pipeline.py:507
+                with torch.cuda.stream(self._memcpy_stream):
+                    self._batch_ip2 = self._to_device(next(dataloader_iter, None), True)
+            with label("## wait_for_batch ##"):  # train_pipeline.py:516
+                torch.cuda.current_stream().wait_stream(self._data_dist_stream)
         else:
             self._batch_ip2 = self._to_device(next(dataloader_iter, None), False)
         batch = self._batch_i
@@ -172,7 +176,8 @@ class TrainPipelineSparseDist:
             # stream long after `progress` has dropped its reference to the batch
             batch.record_stream(torch.cuda.current_stream())
         if self._model.training:
-            self._optimizer.zero_grad()
+            with label("## zero_grad ##"):  # train_pipeline.py:504
+                self._optimizer.zero_grad()
         fwd_event = torch.cuda.Event() if self._data_dist_stream is not None else None
         if fwd_event is not None:
             fwd_event.record()
@@ -184,36 +189,42 @@ class TrainPipelineSparseDist:
                 return
             started[0] = True
             if self._batch_ip1 is not None and self._data_dist_stream is not None:
-                with torch.cuda.stream(self._data_dist_stream):
-                    self._data_dist_stream.wait_stream(self._memcpy_stream)
-                    self._data_dist_stream.wait_event(fwd_event)
-                    self._start_data_dist(self._batch_ip1)
+                with label("## sparse_data_dist ##"):  # train_pipeline.py:528
+                    with torch.cuda.stream(self._data_dist_stream):
+                        self._data_dist_stream.wait_stream(self._memcpy_stream)
+                        self._data_dist_stream.wait_event(fwd_event)
+                        self._start_data_dist(self._batch_ip1)
 
         root = self._model.module if isinstance(self._model, DistributedModelParallel) else self._model
         explicit = self._model.training and hasattr(root, "set_between_forward_and_backward")
         if explicit:
             # a model that runs its own backward inside forward (models/dlrm.py explicit step) calls this between the two
+            # (and labels its own "## forward ##" / "## backward ##" ranges then)
             root.set_between_forward_and_backward(start_next_input_dist)
-        losses, output = self._model(batch)
+        with label("## forward ##"):  # train_pipeline.py:520 (an explicit step nests "## backward ##" inside)
+            losses, output = self._model(batch)
         start_next_input_dist()
         backward_done = explicit and root.take_backward_done()
         if self._model.training and backward_done:
-            if hasattr(root, "finish_dense_grads"):
-                root.finish_dense_grads()
-            self._optimizer.step()
+            with label("## optimizer ##"):  # train_pipeline.py:550
+                if hasattr(root, "finish_dense_grads"):
+                    root.finish_dense_grads()
+                self._optimizer.step()
         elif self._model.training:
-            if self._wgrad_overlap:
-                from ..modules.mlp import _WgradOverlap
+            with label("## backward ##"):  # train_pipeline.py:546
+                if self._wgrad_overlap:
+                    from ..modules.mlp import _WgradOverlap
 
-                _WgradOverlap.enable(self._device)  # for this backward only: joined right below
-                try:
+                    _WgradOverlap.enable(self._device)  # for this backward only: joined right below
+                    try:
+                        torch.sum(losses, dim=0).backward()
+                    finally:
+                        _WgradOverlap.disable()
+                else:
                     torch.sum(losses, dim=0).backward()
-                finally:
-                    _WgradOverlap.disable()
-            else:
-                torch.sum(losses, dim=0).backward()
-            if hasattr(root, "finish_dense_grads"):
-                root.finish_dense_grads()  # flat-buffer gradient all-reduce of graphed segments (models/dlrm.py)
-            self._optimizer.step()
+            with label("## optimizer ##"):
+                if hasattr(root, "finish_dense_grads"):
+                    root.finish_dense_grads()  # flat-buffer gradient all-reduce of graphed segments (models/dlrm.py)
+                self._optimizer.step()
         self._batch_i, self._batch_ip1 = self._batch_ip1, self._batch_ip2
         return output  # as the reference (train_pipeline.py:558): the model's second result, not the losses

@@ -10,6 +10,7 @@ import torch
 from torch import nn
 
 from ..modules.mlp import MLP, LinearOut
+from ..profiling import label
 from ..sparse.jagged_tensor import KeyedJaggedTensor, KeyedTensor
 
 
@@ -454,20 +455,21 @@ class DLRMTrain(nn.Module):
             if between is not None:
                 between()
             # backward: d(loss) = 1
-            ones = getattr(self, "_loss_grad_ready", False)
-            if not ones:
-                g_head.static_grad_outputs[0].fill_(1.0)
-                object.__setattr__(self, "_loss_grad_ready", True)
-            g_head.bwd_graph.replay()  # ends with the gradient of the pooled embeddings
-            step.start_backward(g_head.static_grad_inputs[1].view(B, -1))  # pack + gradient all-to-all (+ replicated tables)
-            if getattr(g_head, "bwd_graph2", None) is not None:
-                g_head.bwd_graph2.replay()  # the head's weight gradients, while the all-to-all is in flight
-            if g_head.after_backward is not None:
-                g_head.after_backward()  # all-reduce of the head's slice of the flat gradient
-            g_dense.bwd_graph.replay()  # its grad_output buffer IS the head's gradient w.r.t. the bottom-MLP output
-            if g_dense.after_backward is not None:
-                g_dense.after_backward()
-            step.finish_backward()
+            with label("## backward ##"):  # train_pipeline.py:546
+                ones = getattr(self, "_loss_grad_ready", False)
+                if not ones:
+                    g_head.static_grad_outputs[0].fill_(1.0)
+                    object.__setattr__(self, "_loss_grad_ready", True)
+                g_head.bwd_graph.replay()  # ends with the gradient of the pooled embeddings
+                step.start_backward(g_head.static_grad_inputs[1].view(B, -1))  # pack + gradient all-to-all (+ replicated tables)
+                if getattr(g_head, "bwd_graph2", None) is not None:
+                    g_head.bwd_graph2.replay()  # the head's weight gradients, while the all-to-all is in flight
+                if g_head.after_backward is not None:
+                    g_head.after_backward()  # all-reduce of the head's slice of the flat gradient
+                g_dense.bwd_graph.replay()  # its grad_output buffer IS the head's gradient w.r.t. the bottom-MLP output
+                if g_dense.after_backward is not None:
+                    g_dense.after_backward()
+                step.finish_backward()
         object.__setattr__(self, "_backward_done", True)
         object.__setattr__(self, "explicit_steps", getattr(self, "explicit_steps", 0) + 1)  # for tests / bench.py's line
         return loss.detach(), (loss.detach(), logits.detach(), batch.labels.detach())
