@@ -384,8 +384,11 @@ def main(args):
                 torch.sum(c.abs(), dtype=torch.float64) for c in x.view(-1).split(1 << 28))
         return acc
 
-    emb_sum = sums(w for _, (w, _) in shard.local_shards().items())
-    dp_sum = sums(w for _, w in shard.dp_tables().items())
+    if sort_giveups == 0:
+        emb_sum = sums(w for _, (w, _) in shard.local_shards().items())
+        dp_sum = sums(w for _, w in shard.dp_tables().items())
+    else:  # the module's accessors raise KernelFaultError now (rightly): the run is reported invalid below instead
+        emb_sum, dp_sum = sums([]), sums([])
     dense_sum = sums(q for n, q in model.named_parameters() if "_dp_module" not in n)
     replicas_identical = True
     if world > 1:
