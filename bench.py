@@ -82,6 +82,9 @@ def parse():
                     help="shard the N largest tables row-wise.  Default (-1): at N > 1 the pinned mixed plan of BASELINE "
                          "config 3 / SURVEY.md §8d (the 4 largest tables row-wise, the rest table-wise or replicated), "
                          "at N = 1 none.  0 = the planner's own choice (row-wise only for capacity)")
+    ap.add_argument("--rw-input-dist", choices=["auto", "windows", "bucketize"], default="auto",
+                    help="input dist of row-wise features: row windows (sync-free, every rank receives every id) or the "
+                         "reference's bucketized exchange; auto = windows at this workload's pooling factor of 1")
     ap.add_argument("--spawn", action="store_true",
                     help="start the rank processes through the built-in launcher even for --gpus 1")
     ap.add_argument("--tuned-gemms", choices=["on", "off"], default="on",
@@ -272,7 +275,7 @@ def main(args):
 
     model = DistributedModelParallel(
         module=train_model, env=env, device=dev,
-        sharders=[EmbeddingBagCollectionSharder(fused_params={"learning_rate": args.lr})],
+        sharders=[EmbeddingBagCollectionSharder(fused_params={"learning_rate": args.lr}, rw_input_dist=args.rw_input_dist)],
         planner=EmbeddingShardingPlanner(Topology(env.world_size), num_row_wise=num_rw or None),
         init_data_parallel=False)
     shard = model.sharded_modules()[0]
@@ -543,7 +546,8 @@ def main(args):
                                 "source": ("pinned mixed plan (BASELINE config 3, SURVEY.md §8d)" if args.row_wise < 0 and world > 1
                                            else "torchrec_amd planner" if args.row_wise <= 0 else "--row-wise")},
                        "ids": f"zipf({args.zipf})" if args.zipf else "uniform", "row_cap": args.row_cap or None,
-                       "distinct_batches": args.num_batches, "seed": args.seed, "data_ranks": data_ranks},
+                       "distinct_batches": args.num_batches, "seed": args.seed, "data_ranks": data_ranks,
+                       "rw_input_dist": shard._rw_mode_active if n_rw else None},
             "checks": checks, "binding": binding, "roofline": roofline, "cpu_baseline": cpu,
         }
         # a run whose kernels gave up, saw out-of-range ids or let the replicas drift measured the wrong computation:

@@ -51,12 +51,12 @@ def _stage_a2a_through_host():
     dist.all_to_all_single = a2a
 
 
-def _data(W, fixed_len, weighted, seed=11):
+def _data(W, fixed_len, weighted, seed=11, max_len=3):
     rng = np.random.default_rng(seed)
     F = len(ROWS)
     per_rank = []
     for _ in range(W):
-        lengths = (np.full(F * B_LOCAL, fixed_len) if fixed_len else rng.integers(0, 4, size=F * B_LOCAL)).astype(np.int32)
+        lengths = (np.full(F * B_LOCAL, fixed_len) if fixed_len else rng.integers(0, max_len + 1, size=F * B_LOCAL)).astype(np.int32)
         vals = np.concatenate([rng.integers(0, ROWS[f], size=int(lengths[f * B_LOCAL:(f + 1) * B_LOCAL].sum()))
                                for f in range(F)]).astype(np.int64)
         wts = (rng.random(vals.size).astype(np.float32) + 0.5) if weighted else None
@@ -66,7 +66,7 @@ def _data(W, fixed_len, weighted, seed=11):
     return per_rank, init
 
 
-def _build_sharded(W, backend_env, weighted, n_rw, dp_max_rows, offload=False, adagrad=False, mean=False):
+def _build_sharded(W, backend_env, weighted, n_rw, dp_max_rows, offload=False, adagrad=False, mean=False, rw_mode=None):
     from torchrec_amd.distributed.embeddingbag import ShardedEmbeddingBagCollection
     from torchrec_amd.distributed.planner import EmbeddingShardingPlanner, ParameterConstraints, Topology
     from torchrec_amd.modules.embedding_configs import EmbeddingBagConfig
@@ -89,7 +89,7 @@ def _build_sharded(W, backend_env, weighted, n_rw, dp_max_rows, offload=False, a
     if adagrad:
         from fbgemm_gpu.split_embedding_configs import EmbOptimType
         fused.update({"optimizer": EmbOptimType.EXACT_ROWWISE_ADAGRAD, "eps": 1e-3})
-    sebc = ShardedEmbeddingBagCollection(ebc, plan, backend_env, fused, torch.device("cuda", 0))
+    sebc = ShardedEmbeddingBagCollection(ebc, plan, backend_env, fused, torch.device("cuda", 0), rw_input_dist=rw_mode)
     return keys, plan, sebc
 
 
@@ -128,7 +128,8 @@ def _run_rank(sebc, keys, per_rank, init, rank, W, fixed_len, weighted):
     return vals_out.detach().cpu().numpy().copy(), shards
 
 
-def _worker(rank, W, port, fixed_len, weighted, n_rw, dp_max_rows, ret, offload=False, adagrad=False, mean=False):
+def _worker(rank, W, port, fixed_len, weighted, n_rw, dp_max_rows, ret, offload=False, adagrad=False, mean=False,
+            rw_mode=None, max_len=3):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
@@ -137,9 +138,9 @@ def _worker(rank, W, port, fixed_len, weighted, n_rw, dp_max_rows, ret, offload=
         _stage_a2a_through_host()
         from torchrec_amd.distributed.types import ShardingEnv
 
-        per_rank, init = _data(W, fixed_len, weighted)
+        per_rank, init = _data(W, fixed_len, weighted, max_len=max_len)
         keys, plan, sebc = _build_sharded(W, ShardingEnv.from_process_group(dist.group.WORLD), weighted, n_rw, dp_max_rows,
-                                          offload, adagrad, mean)
+                                          offload, adagrad, mean, rw_mode)
         out, shards = _run_rank(sebc, keys, per_rank, init, rank, W, fixed_len, weighted)
         if adagrad:  # per-table row-wise state of the local shards (batched_embedding_kernel.py:133-148)
             states = sebc._emb_module.split_optimizer_states()
@@ -149,17 +150,18 @@ def _worker(rank, W, port, fixed_len, weighted, n_rw, dp_max_rows, ret, offload=
             assert plan["t3"].compute_kernel == "batched_fused_uvm_caching" and sebc._emb_module._cache is not None
         ret[rank] = (out, shards, {n: p.sharding_type for n, p in plan.items()})
         ret[f"errors{rank}"] = sebc._emb_module.bounds_check_errors() if sebc._emb_module is not None else 0
+        ret[f"rw_mode{rank}"] = sebc._rw_mode_active
     finally:
         dist.destroy_process_group()
 
 
-def _check_against_oracle(ret, W, fixed_len, weighted, n_rw, dp_max_rows, adagrad=False, mean=False):
+def _check_against_oracle(ret, W, fixed_len, weighted, n_rw, dp_max_rows, adagrad=False, mean=False, max_len=3):
     from _util import oracle_backward_mixed, oracle_forward_mixed
     from oracle import oracle
 
     feat_mean = [(i % 2 == 1) if mean == "mixed" else bool(mean) for i in range(len(ROWS))]
 
-    per_rank, init = _data(W, fixed_len, weighted)
+    per_rank, init = _data(W, fixed_len, weighted, max_len=max_len)
     F, B = len(ROWS), B_LOCAL
     tabs = oracle.Tables(ROWS, [D] * F)
     for t in range(F):
@@ -218,6 +220,24 @@ def test_sharded_world2_on_one_gpu(fixed_len, weighted, n_rw, dp_max_rows):
     ret = ResultStore()
     mp.spawn(_worker, args=(W, _free_port(), fixed_len, weighted, n_rw, dp_max_rows, ret), nprocs=W, join=True)
     _check_against_oracle(ret, W, fixed_len, weighted, n_rw, dp_max_rows)
+
+
+@pytest.mark.parametrize("fixed_len,weighted,n_rw,dp_max_rows,offload,adagrad", [
+    (1, False, 2, 10, False, False), (0, False, 3, 0, False, False), (0, True, 2, 10, False, False), (1, True, 6, 0, False, False),
+    (5, False, 2, 0, False, False), (0, False, 1, 10, True, True)])
+@pytest.mark.parametrize("rw_mode", ["bucketize", "windows"])
+def test_row_wise_input_dist_modes_world2_on_one_gpu(fixed_len, weighted, n_rw, dp_max_rows, offload, adagrad, rw_mode):
+    """the bucketized row-wise input dist of the POOLED path with the real kernels
+    (block_bucketize_sparse_features -> lengths / ids exchange -> lookup on LOCAL rows without a row window) next to the
+    row-window one: pooling factor 1, ragged bags of up to 6 ids, per-sample weights, all-row-wise plans, row-wise shards
+    behind the HBM row cache with fused row-wise Adagrad — sharded == unsharded (oracle), zero bounds errors.
+    Reference: embedding_sharding.py:121-184, sharding/rw_sharding.py:229-236, test_model_parallel_base.py:148-294."""
+    W = 2
+    ret = ResultStore()
+    mp.spawn(_worker, args=(W, _free_port(), fixed_len, weighted, n_rw, dp_max_rows, ret, offload, adagrad, False, rw_mode, 6),
+             nprocs=W, join=True)
+    assert ret["rw_mode0"] == rw_mode and ret["rw_mode1"] == rw_mode
+    _check_against_oracle(ret, W, fixed_len, weighted, n_rw, dp_max_rows, adagrad=adagrad, max_len=6)
 
 
 def _rccl_worker(rank, port, fixed_len, weighted, dp_max_rows, ret):

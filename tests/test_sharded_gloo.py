@@ -44,7 +44,7 @@ def _global_data(W, B_local, fixed_len, weighted, seed=3):
     return per_rank, init
 
 
-def _worker(rank, W, port, fixed_len, weighted, n_rw, ret, dp_max_rows=0, mean=False):
+def _worker(rank, W, port, fixed_len, weighted, n_rw, ret, dp_max_rows=0, mean=False, rw_mode=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=W)
@@ -72,7 +72,8 @@ def _worker(rank, W, port, fixed_len, weighted, n_rw, ret, dp_max_rows=0, mean=F
         plan = EmbeddingShardingPlanner(Topology(W, "cpu"), num_row_wise=n_rw, dp_max_rows=dp_max_rows).plan_tables(tables)
         env = ShardingEnv.from_process_group(dist.group.WORLD)
         sebc = ShardedEmbeddingBagCollection(ebc, plan, env, {"learning_rate": LR}, torch.device("cpu"),
-                                             tbe_factory=oracle_tbe_factory, dp_tbe_factory=oracle_dp_tbe_factory)
+                                             tbe_factory=oracle_tbe_factory, dp_tbe_factory=oracle_dp_tbe_factory,
+                                             rw_input_dist=rw_mode)
         # load the global initial weights into the local shards / replicas
         for name, (w, row0) in sebc.local_shards().items():
             t = int(name[1:])
@@ -101,16 +102,51 @@ def _worker(rank, W, port, fixed_len, weighted, n_rw, ret, dp_max_rows=0, mean=F
                 sebc._dp_module.weights -= LR * g
             for n, w in sebc.dp_tables().items():
                 shards[n] = (w.clone().numpy(), 0)
-        ret[rank] = (vals_out.detach().numpy().copy(), shards, {n: p.sharding_type for n, p in plan.items()})
+        ret[rank] = (vals_out.detach().numpy().copy(), shards, {n: p.sharding_type for n, p in plan.items()},
+                     sebc._rw_mode_active)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fixed_len,weighted,n_rw", [(1, False, 2), (1, True, 5), (0, False, 1), (0, True, 3), (4, False, 2),
+                                                     (6, True, 1)])
+@pytest.mark.parametrize("rw_mode", ["windows", "bucketize", "auto"])
+def test_row_wise_input_dist_modes_world2(fixed_len, weighted, n_rw, rw_mode):
+    """the bucketized row-wise input dist of the POOLED path (block_bucketize + lengths / ids
+    exchange, embedding_sharding.py:121-184) next to the row-window one; both must give the unsharded result.  auto:
+    windows for a host-known pooling factor <= 2, bucketize for longer or data-dependent bags."""
+    ret = test_sharded_equals_unsharded_world2(fixed_len, weighted, n_rw, 10 if n_rw <= 3 else 0, False, rw_mode=rw_mode)
+    want = rw_mode if rw_mode != "auto" else ("windows" if 0 < fixed_len <= 2 else "bucketize")
+    assert ret[0][3] == want and ret[1][3] == want
+
+
+def test_bucketized_input_dist_refuses_mean_pooled_row_wise_tables():
+    import _cpu_ops
+    _cpu_ops.register()
+    from _oracle_tbe import oracle_tbe_factory
+    from torchrec_amd.distributed.embeddingbag import ShardedEmbeddingBagCollection
+    from torchrec_amd.distributed.planner import EmbeddingShardingPlanner, Topology
+    from torchrec_amd.distributed.types import ShardingEnv
+    from torchrec_amd.modules.embedding_configs import EmbeddingBagConfig, PoolingType
+    from torchrec_amd.modules.embedding_modules import EmbeddingBagCollection
+
+    tables = [EmbeddingBagConfig(name="t0", embedding_dim=8, num_embeddings=40, feature_names=["f0"], pooling=PoolingType.MEAN)]
+    plan = EmbeddingShardingPlanner(Topology(2, "cpu"), num_row_wise=1, dp_max_rows=0).plan_tables(tables)
+    assert plan["t0"].sharding_type == "row_wise"
+    ebc = EmbeddingBagCollection(tables, device=torch.device("meta"))
+    with pytest.raises(NotImplementedError, match="MEAN"):
+        ShardedEmbeddingBagCollection(ebc, plan, ShardingEnv.from_local(2, 0), {}, torch.device("cpu"),
+                                      tbe_factory=oracle_tbe_factory, rw_input_dist="bucketize")
+    auto = ShardedEmbeddingBagCollection(ebc, plan, ShardingEnv.from_local(2, 0), {}, torch.device("cpu"),
+                                         tbe_factory=oracle_tbe_factory, rw_input_dist="auto")
+    assert auto._rw_mean is True  # auto keeps such collections on row windows
 
 
 @pytest.mark.parametrize("fixed_len,weighted,n_rw,dp_max_rows,mean", [
     (1, False, 1, 0, False), (2, True, 2, 0, False), (0, False, 1, 0, False), (0, True, 0, 0, False),
     (1, False, 5, 0, False), (1, False, 0, 10, False), (0, True, 1, 25, False), (2, False, 0, 100, False),
     (0, False, 2, 10, True), (3, False, 5, 0, True), (0, False, 2, 10, "mixed"), (0, True, 1, 0, "mixed"), (2, False, 0, 25, "mixed")])
-def test_sharded_equals_unsharded_world2(fixed_len, weighted, n_rw, dp_max_rows, mean):
+def test_sharded_equals_unsharded_world2(fixed_len, weighted, n_rw, dp_max_rows, mean, rw_mode=None):
     """mean=True: MEAN pooling over row-wise shards — every rank divides its partial sum by the FULL bag length
     (all ids travel to every rank, rows outside its block are masked), so the partial pools still add up."""
     from oracle import oracle
@@ -121,7 +157,7 @@ def test_sharded_equals_unsharded_world2(fixed_len, weighted, n_rw, dp_max_rows,
     feat_mean = [(i % 2 == 1) if mean == "mixed" else bool(mean) for i in range(len(ROWS))]
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(W, _free_port(), fixed_len, weighted, n_rw, ret, dp_max_rows, mean), nprocs=W, join=True)
+    mp.spawn(_worker, args=(W, _free_port(), fixed_len, weighted, n_rw, ret, dp_max_rows, mean, rw_mode), nprocs=W, join=True)
     per_rank, init = _global_data(W, 6, fixed_len, weighted)
     # unsharded oracle on each rank's batch (forward), then ONE backward over the global batch with
     # grads / W (GRADIENT_DIVISION, comm_ops.py:527-528)
@@ -157,6 +193,7 @@ def test_sharded_equals_unsharded_world2(fixed_len, weighted, n_rw, dp_max_rows,
     for t in range(F):
         replicas = W if kinds[f"t{t}"] == "data_parallel" else 1
         assert seen_rows[t] == ROWS[t] * replicas, "sharded rows live on exactly one rank, replicated tables on all"
+    return dict(ret)
 
 
 def test_planner_criteo_plans():

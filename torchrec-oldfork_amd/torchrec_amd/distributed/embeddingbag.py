@@ -21,6 +21,12 @@ EmbeddingBagCollectionSharder (:489-515).  The data path is re-designed for xGMI
                                                                TW columns, sum RW partials in rank order)
   backward: recat copy + a2a / all-gather, grads / W           tbe_pooled_exchange_pack (x 1/W fused) + ONE a2a
 
+Row-wise input dist has a second, selectable form (`rw_input_dist`): "bucketize" = the reference's — ids of row-wise
+features bucketized by row block (block_bucketize_sparse_features, embedding_sharding.py:121-184), every rank receives only
+its own block's ids as LOCAL rows, lengths exchange + one D2H read of the counts + values exchange.  "windows" (above) is
+sync-free but sends, linearizes and sorts W x the row-wise ids; "auto" picks windows for a host-known pooling factor <= 2
+and bucketize for longer or data-dependent bags (tools/rankbench.py, DESIGN.md §4 have the numbers).
+
 Tiny tables can be DATA_PARALLEL (replicated): a dense-gradient TBE looks them up for the local
 batch and writes straight into its columns of the output matrix (no exchange, no cat); their
 gradient is all-reduced by DDP like any dense parameter (sharding/dp_sharding.py in the reference).
@@ -336,9 +342,14 @@ class ShardedEmbeddingBagCollection(nn.Module):
         device: Optional[torch.device] = None,
         tbe_factory: Optional[Callable] = None,
         dp_tbe_factory: Optional[Callable] = None,
+        rw_input_dist: Optional[str] = None,
     ) -> None:
         super().__init__()
         self._env = env
+        rw_input_dist = rw_input_dist or os.environ.get("TORCHREC_AMD_RW_INPUT_DIST", "auto")
+        if rw_input_dist not in ("auto", "windows", "bucketize"):
+            raise ValueError("rw_input_dist must be auto, windows or bucketize")
+        self._rw_input_dist = rw_input_dist
         self._pg = env.process_group
         W, me = env.world_size, env.rank
         self._world_size, self._rank = W, me
@@ -386,6 +397,18 @@ class ShardedEmbeddingBagCollection(nn.Module):
         self._F_local = len(local_feats[me])
         self._send_feature_order = [g for lf in local_feats for g in lf]
         self._send_feats_per_rank = [len(lf) for lf in local_feats]
+        # bucketized row-wise input dist: row-wise features (bucketized, one block per destination) and the table-wise
+        # features in destination order travel as separate pieces of one exchange
+        self._rw_feats = rw_feats
+        self._tw_send_order = [g for r in range(W) for g in local_feats[r] if kind[g_table[g]] != -1]
+        self._tw_per_rank = [sum(1 for g in local_feats[r] if kind[g_table[g]] != -1) for r in range(W)]
+        self._rw_block_sizes = torch.tensor([rw_block_size(cfgs[g_table[g]].num_embeddings, W) for g in rw_feats],
+                                            dtype=torch.int64, device=self._device if self._device.type != "meta" else "cpu")
+        self._rw_mean = any(pooling_type_to_pooling_mode(cfgs[g_table[g]].pooling) == 1 for g in rw_feats)
+        if self._rw_mean and rw_input_dist == "bucketize":
+            raise NotImplementedError(
+                "rw_input_dist='bucketize' with MEAN-pooled row-wise tables: a rank would divide its partial sum by the number "
+                "of ids in ITS row block, not by the bag length; use 'windows' (or 'auto', which does) for such collections")
         # exchange descriptors (batch-independent part)
         feat_src, feat_slab_col = [0] * Fg, [0] * Fg
         for r in range(W):
@@ -438,14 +461,18 @@ class ShardedEmbeddingBagCollection(nn.Module):
         fused_params = dict(fused_params or {})
         factory = tbe_factory or _default_tbe_factory
         self._emb_module = None
+        self._row_windows = None
+        self._rw_mode_active = "windows"
         if self._local_tables:
             self._emb_module = factory(
                 [(max(lt.local_rows, 0), lt.cfg.embedding_dim, lt.compute_kernel) for lt in self._local_tables],
                 ftm_local * W, pooling_type_to_pooling_mode(self._local_tables[ftm_local[0]].cfg.pooling), dev, fused_params)
             if self._exchange:
                 self._emb_module.set_a2a_output_layout(W)
+            self._row_windows = (win_first * W, win_global * W) if self._has_rw else None
+            self._rw_mode_active = "windows"
             if self._has_rw:
-                self._emb_module.set_row_windows(win_first * W, win_global * W)
+                self._emb_module.set_row_windows(*self._row_windows)
             local_pooling = [pooling_type_to_pooling_mode(self._local_tables[i].cfg.pooling) for i in ftm_local]
             if len(set(local_pooling)) > 1:
                 self._emb_module.set_feature_pooling(local_pooling * W)
@@ -690,12 +717,141 @@ class ShardedEmbeddingBagCollection(nn.Module):
         sub = features.permute(order, None)
         return sub.values(), sub.offsets().long(), (sub.weights_or_none() if weights is not None else None)
 
+    # ---- row-wise input dist: row windows (sync-free, W x the ids) or bucketized (the reference's) --------------------
+    AUTO_WINDOWS_MAX_POOLING = 2  # "auto": host-known pooling factor <= this -> windows; longer / data-dependent -> bucketize
+
+    def _pick_rw_mode(self, features: KeyedJaggedTensor) -> str:
+        if not self._rw_feats or self._rw_input_dist == "windows" or self._rw_mean:
+            return "windows"
+        if self._rw_input_dist == "bucketize":
+            return "bucketize"
+        fixed = features.fixed_lengths()
+        if fixed is not None and len(set(fixed)) == 1 and 0 < fixed[0] <= self.AUTO_WINDOWS_MAX_POOLING:
+            return "windows"
+        return "bucketize"
+
+    def _set_rw_mode(self, mode: str) -> None:
+        """windows: the lookup sees GLOBAL ids of row-wise features and masks with its shard's row window;
+        bucketize: it sees the LOCAL rows of its own block only (no window)."""
+        if mode == self._rw_mode_active:
+            return
+        if self._emb_module is not None and self._row_windows is not None:
+            if mode == "windows":
+                self._emb_module.set_row_windows(*self._row_windows)
+            else:
+                self._emb_module.set_row_windows(None)
+        self._rw_mode_active = mode
+
+    def _bucketize_perm(self, keys: List[str]):
+        ck = ("bkt", tuple(keys))
+        hit = self._kjt_cache.get(ck)
+        if hit is None:
+            pos = {k: i for i, k in enumerate(keys)}
+            missing = [n for n in self._feature_names if n not in pos]
+            if missing:
+                raise KeyError(f"KeyedJaggedTensor is missing features {missing[:3]}...")
+            rw_pos = [pos[self._feature_names[g]] for g in self._rw_feats]
+            tw_pos = [pos[self._feature_names[g]] for g in self._tw_send_order]
+            dev = self._device
+            tw_first = [0]
+            for n in self._tw_per_rank:
+                tw_first.append(tw_first[-1] + n)
+            hit = (rw_pos, torch.tensor(rw_pos, dtype=torch.int32, device=dev), tw_pos,
+                   torch.tensor(tw_pos, dtype=torch.int32, device=dev), tw_first)
+            self._kjt_cache[ck] = hit
+        return hit
+
+    def _input_dist_bucketized(self, features: KeyedJaggedTensor, dp_in) -> Awaitable[SparseFeaturesDist]:
+        """The reference's row-wise input dist (bucketize_kjt_before_all2all + KJTAllToAll: embedding_sharding.py:121-184,
+        dist_data.py:137-524) folded into this collection's ONE exchange: the piece for destination r is
+        [bucket r of the row-wise features | the table-wise features r owns], lengths first (static sizes), then ONE D2H
+        read of the piece / receive counts (the reference reads them in two places: dist_data.py:396-398,
+        jagged_tensor.py:502-509), then the ids (and per-sample weights).  The receiver's layout is the usual
+        [src rank][local feature][sample]; row-wise ids arrive as LOCAL rows of this rank's block."""
+        W, B = self._world_size, features.stride()
+        rw_pos, rw_pos_t, tw_pos, tw_pos_t, tw_first = self._bucketize_perm(features.keys())
+        n_rw = len(rw_pos)
+        weighted = self._is_weighted and features.weights_or_none() is not None
+        rw = features.permute(rw_pos, rw_pos_t)
+        with label("## bucketize_kjt_before_all2all ##"):
+            blocks = self._rw_block_sizes.to(device=rw.values().device, dtype=rw.values().dtype)
+            bl, bi, bw, _, _ = torch.ops.fbgemm.block_bucketize_sparse_features(
+                lengths=rw.lengths(), indices=rw.values(), bucketize_pos=False, sequence=False, block_sizes=blocks,
+                my_size=W, weights=rw.weights_or_none() if weighted else None)
+        tw = features.permute(tw_pos, tw_pos_t) if tw_pos else None
+        tw_len = tw.lengths() if tw is not None else None
+        pieces = []
+        for r in range(W):
+            pieces.append(bl[r * n_rw * B:(r + 1) * n_rw * B])
+            if tw is not None and self._tw_per_rank[r]:
+                pieces.append(tw_len[tw_first[r] * B:tw_first[r + 1] * B].to(bl.dtype))
+        send_l = torch.cat(pieces)
+        # piece boundaries inside the bucketized / table-wise id arrays, as device prefix sums
+        off_b = torch.ops.fbgemm.asynchronous_complete_cumsum(bl)[::n_rw * B].to(torch.int64)  # [W + 1]
+        if tw is not None:
+            ck = ("twb", B)
+            idx_t = self._kjt_cache.get(ck)
+            if idx_t is None:
+                idx_t = torch.tensor([f * B for f in tw_first], dtype=torch.int64, device=self._device)
+                self._kjt_cache[ck] = idx_t
+            off_t = tw.offsets().to(torch.int64).index_select(0, idx_t)  # [W + 1]
+        else:
+            off_t = torch.zeros(W + 1, dtype=torch.int64, device=off_b.device)
+        len_in = [(n_rw + n) * B for n in self._tw_per_rank]
+        len_out = [self._F_local * B] * W
+        if self._exchange:
+            recv_l = torch.empty(sum(len_out), dtype=send_l.dtype, device=send_l.device)
+            with label("## all2all_data:lengths ##"):  # dist_data.py:366
+                dist.all_to_all_single(recv_l, send_l, len_out, len_in, group=self._pg)
+        else:
+            recv_l = send_l
+        with label("## all2all_data:split length for a2a ##"):  # dist_data.py:388-398: the D2H read
+            host = torch.cat([off_b, off_t, recv_l.view(W, -1).sum(dim=1).to(torch.int64)]).cpu().tolist()
+        ob, ot, val_out = host[:W + 1], host[W + 1:2 * W + 2], host[2 * W + 2:]
+        val_in = [(ob[r + 1] - ob[r]) + (ot[r + 1] - ot[r]) for r in range(W)]
+
+        def assemble(b_arr, t_arr):
+            parts = []
+            for r in range(W):
+                parts.append(b_arr[ob[r]:ob[r + 1]])
+                if t_arr is not None and ot[r + 1] > ot[r]:
+                    parts.append(t_arr[ot[r]:ot[r + 1]])
+            return torch.cat(parts) if parts else b_arr[:0]
+
+        send_v = assemble(bi, tw.values() if tw is not None else None)
+        send_w = assemble(bw, tw.weights() if tw is not None else None) if weighted else None
+        if self._exchange:
+            recv_v = torch.empty(sum(val_out), dtype=send_v.dtype, device=send_v.device)
+            with label("## all2all_data:indices ##"):  # dist_data.py:190
+                wk = dist.all_to_all_single(recv_v, send_v, val_out, val_in, group=self._pg, async_op=True)
+            recv_w, wk2 = None, None
+            if send_w is not None:
+                recv_w = torch.empty(sum(val_out), dtype=send_w.dtype, device=send_w.device)
+                with label("## all2all_data:weights ##"):  # dist_data.py:213
+                    wk2 = dist.all_to_all_single(recv_w, send_w, val_out, val_in, group=self._pg, async_op=True)
+        else:
+            recv_v, recv_w, wk, wk2 = send_v, send_w, None, None
+
+        def finish() -> SparseFeaturesDist:
+            if wk is not None:
+                wk.wait()
+            if wk2 is not None:
+                wk2.wait()
+            offsets = torch.ops.fbgemm.asynchronous_complete_cumsum(recv_l).long()
+            return SparseFeaturesDist(recv_v, offsets, recv_w, B, dp_in)
+
+        return _InputDistAwaitable(finish)
+
     def input_dist(self, features: KeyedJaggedTensor) -> Awaitable[SparseFeaturesDist]:
         W, B = self._world_size, features.stride()
+        dp_in = self._dp_inputs(features)
+        mode = self._pick_rw_mode(features)
+        self._set_rw_mode(mode)
+        if mode == "bucketize":
+            return self._input_dist_bucketized(features, dp_in)
         order, order_t = self._send_perm(features.keys())
         fixed = features.fixed_lengths()
         weights = features.weights_or_none() if self._is_weighted else None
-        dp_in = self._dp_inputs(features)
         if fixed is not None and len(set(fixed)) == 1 and fixed[0] > 0:
             L = fixed[0]
             nkeys = len(features.keys())
@@ -888,15 +1044,16 @@ class EmbeddingBagCollectionSharder:
     (torchrec/distributed/embeddingbag.py:489-515)."""
 
     def __init__(self, fused_params: Optional[Dict[str, Any]] = None, tbe_factory: Optional[Callable] = None,
-                 dp_tbe_factory: Optional[Callable] = None) -> None:
+                 dp_tbe_factory: Optional[Callable] = None, rw_input_dist: Optional[str] = None) -> None:
         self.fused_params = fused_params
         self.tbe_factory = tbe_factory
         self.dp_tbe_factory = dp_tbe_factory
+        self.rw_input_dist = rw_input_dist  # "auto" | "windows" | "bucketize" (ShardedEmbeddingBagCollection)
 
     def shard(self, module: EmbeddingBagCollection, params: Dict[str, ParameterSharding], env: ShardingEnv,
               device: Optional[torch.device] = None) -> ShardedEmbeddingBagCollection:
         return ShardedEmbeddingBagCollection(module, params, env, self.fused_params, device, self.tbe_factory,
-                                             self.dp_tbe_factory)
+                                             self.dp_tbe_factory, self.rw_input_dist)
 
     @property
     def module_type(self):
