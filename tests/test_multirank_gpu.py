@@ -446,7 +446,8 @@ def _e2e_run(model, opt, keys, batches, rank, W, dev, hip_graphs=False):
                 KeyedJaggedTensor.from_fixed_lengths(keys, torch.from_numpy(np.ascontiguousarray(i[:, sl]).reshape(-1)).to(dev),
                                                      [1] * len(keys)),
                 torch.from_numpy(lab[sl]).to(dev)) for d, i, lab in batches]
-    pipe = TrainPipelineSparseDist(model, opt, dev, hip_graphs=hip_graphs)
+    # the flat-gradient graph mode also runs with the next step's lookup prefetched behind the embedding backward
+    pipe = TrainPipelineSparseDist(model, opt, dev, hip_graphs=hip_graphs, prefetch_lookup=bool(hip_graphs))
     model.train()
     it = iter(bl)
     losses = []

@@ -414,7 +414,9 @@ __global__ __launch_bounds__(256, MINW) void bwd_update_kernel(BwdArgs a) {
         for (int v = 0; v < NV; ++v) {
           const int d = (v * G + gl) * 4;
           x[u][v] = (val[u] && d < Du[u]) ? ldc(gp, d, Du[u], gvec) : make_float4(0.f, 0.f, 0.f, 0.f);
-          wr[u][v] = (ABL != 2 && lst[u] && d < Du[u]) ? ldc(wp[u], d, Du[u], vecu[u]) : make_float4(0.f, 0.f, 0.f, 0.f);
+          // the current weight row (not needed when the coalesced gradient is only written out: DENSE_GRAD)
+          wr[u][v] = (ABL != 2 && OPTC != TBE_OPT_DENSE_GRAD && lst[u] && d < Du[u]) ? ldc(wp[u], d, Du[u], vecu[u])
+                                                                                        : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
 #pragma unroll
@@ -729,6 +731,8 @@ static int launch_update(const BwdArgs& a, hipStream_t st) {
       }
     } else if (fast && G == 32 && NV == 1 && oc == TBE_OPT_EXACT_ROWWISE_ADAGRAD) {
       TBE_UPD(TBE_OPT_EXACT_ROWWISE_ADAGRAD, true, 4, 4);
+    } else if (fast && G == 32 && NV == 1 && oc == TBE_OPT_DENSE_GRAD) {
+      TBE_UPD(TBE_OPT_DENSE_GRAD, true, 4, 4);  // the replicated tiny tables of a sharded collection (dense gradient)
     } else {
       TBE_UPD(-1, false, UG, 1);
     }

@@ -678,7 +678,7 @@ class _TBEBase(nn.Module):
 
     def _backward_impl(self, grad_out, indices, offsets, per_sample_weights, B: int,
                        opt: OptimizerArgs, state0_override: Optional[torch.Tensor] = None,
-                       prepared=None, layout=None) -> None:
+                       prepared=None, layout=None, state0_aligned: bool = False) -> None:
         lay = self._get_layout()
         dev = self.current_device
         lib = _lib.load()
@@ -697,8 +697,10 @@ class _TBEBase(nn.Module):
         feat_state0 = state0_override if state0_override is not None else lay.feat_state0
         # TBE_FLAG_UNIFORM_ALIGNED: one dim for every feature, multiple of 4 (table bases are laid
         # out 16-B aligned by _init_tables; out offsets are then multiples of 4 as well)
+        # (with state0_override — the dense-gradient backward — the state bases are rows of a gradient buffer laid out like
+        # the weights: aligned iff that buffer is, which the caller asserts through `state0_aligned`)
         flags = 1 if (len(set(self.dims_per_table)) == 1 and self.max_D % 4 == 0 and stride % 4 == 0
-                      and state0_override is None) else 0
+                      and (state0_override is None or state0_aligned)) else 0
         if per_sample_weights is not None:
             flags |= _FLAG_WEIGHTED  # the sort payload then carries positions too (set in prepare as well)
         with torch.cuda.device(dev):
@@ -786,7 +788,8 @@ class _DenseLookupInto(torch.autograd.Function):
         grad_w = torch.zeros_like(module.weights)
         state0 = module._dense_grad_ptrs(grad_w)
         opt = OptimizerArgs(_OPT_DENSE_GRAD, 0.0, 0.0, 0.0, 0.0, 0.0, 1)
-        module._backward_impl(grad_out, indices, offsets, psw, ctx.B, opt, state0_override=state0, layout=ctx.layout)
+        module._backward_impl(grad_out, indices, offsets, psw, ctx.B, opt, state0_override=state0, layout=ctx.layout,
+                              state0_aligned=grad_w.data_ptr() % 16 == 0)
         return (grad_out, grad_w) + (None,) * 7
 
 
@@ -1071,7 +1074,8 @@ class _DenseLookup(torch.autograd.Function):
         grad_w = torch.zeros_like(module.weights)
         state0 = module._dense_grad_ptrs(grad_w)
         opt = OptimizerArgs(_OPT_DENSE_GRAD, 0.0, 0.0, 0.0, 0.0, 0.0, 1)
-        module._backward_impl(grad_out, indices, offsets, psw, ctx.B, opt, state0_override=state0)
+        module._backward_impl(grad_out, indices, offsets, psw, ctx.B, opt, state0_override=state0,
+                              state0_aligned=grad_w.data_ptr() % 16 == 0)
         return grad_w, None, None, None, None, None
 
 
@@ -1139,12 +1143,20 @@ class DenseTableBatchedEmbeddingBagsCodegen(_TBEBase):
         """Forward without an autograd node: (output, LookupRecord); see the fused class."""
         indices, offsets, per_sample_weights, B = self._check_inputs(indices, offsets, per_sample_weights)
         rec = LookupRecord(indices, offsets, per_sample_weights, B, (into[1], int(into[2])) if into is not None else None)
-        return self._forward_impl(indices, offsets, per_sample_weights, B, into=into), rec
+        out = self._forward_impl(indices, offsets, per_sample_weights, B, into=into)
+        # the gradient-independent half of the backward (linearize + sort: 5 dependent launches, ~25 us of latency for the
+        # ~90 K ids of the replicated tiny tables) starts now on the module's side stream, as the fused module's does
+        mode = self.overlap_backward_sort
+        if mode in (True, "1") or (mode == "auto" and indices.numel() <= self.overlap_backward_sort_max_ids):
+            rec.prepared = self._prepare_backward(indices, offsets, B, per_sample_weights is not None)
+        return out, rec
 
     def backward_no_autograd(self, rec: "LookupRecord", grad_out: torch.Tensor) -> torch.Tensor:
         """The dense gradient of `.weights` for the lookup `rec` describes (what _DenseLookup.backward returns)."""
         grad_w = torch.zeros_like(self.weights)
         opt = OptimizerArgs(_OPT_DENSE_GRAD, 0.0, 0.0, 0.0, 0.0, 0.0, 1)
         self._backward_impl(grad_out, rec.indices, rec.offsets, rec.per_sample_weights, rec.B, opt,
-                            state0_override=self._dense_grad_ptrs(grad_w), layout=rec.layout)
+                            state0_override=self._dense_grad_ptrs(grad_w), prepared=rec.prepared, layout=rec.layout,
+                            state0_aligned=grad_w.data_ptr() % 16 == 0)
+        rec.prepared = None
         return grad_w

@@ -994,10 +994,22 @@ class ExplicitLookupStep:
         self.state: Optional[_ExchangeState] = None
         self._grad: Optional[torch.Tensor] = None
         if owner._exchange:
-            with label("## tbe_lookup ##"):
-                emb, self.rec = owner._emb_module.lookup_no_autograd(dist_input.values, dist_input.offsets, dist_input.weights)
+            # order of the HOST calls: lookup kernel, pooled all-to-all, THEN the backward's side-stream sort (6 launches,
+            # ~60 us of host time): the all-to-all is on the step's critical path, the sort is not
+            m = owner._emb_module
+            can_defer = hasattr(m, "launch_deferred_backward_sort") and not getattr(m, "defer_backward_sort", False)
+            if can_defer:
+                m.defer_backward_sort = True
+            try:
+                with label("## tbe_lookup ##"):
+                    emb, self.rec = m.lookup_no_autograd(dist_input.values, dist_input.offsets, dist_input.weights)
+            finally:
+                if can_defer:
+                    m.defer_backward_sort = False
             self.state = _ExchangeState(owner, dist_input.batch_size)
             self.state.start_forward(emb)
+            if can_defer:
+                m.launch_deferred_backward_sort()
             self._out = None
         else:
             out = owner._alias_output_buffer(dist_input.batch_size)

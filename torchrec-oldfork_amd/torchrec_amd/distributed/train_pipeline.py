@@ -50,7 +50,7 @@ class _PipelinedEBC(torch.nn.Module):
 
 class TrainPipelineSparseDist:
     def __init__(self, model: torch.nn.Module, optimizer: Any, device: torch.device, hip_graphs: bool = False,
-                 wgrad_overlap: Optional[bool] = None) -> None:
+                 wgrad_overlap: Optional[bool] = None, prefetch_lookup: Optional[bool] = None) -> None:
         self._model, self._optimizer, self._device = model, optimizer, device
         # wgrad_overlap: the dense layers' weight-gradient GEMMs of an eager step run on a side stream, joined right
         # after backward (modules/mlp.py _WgradOverlap).  Opt-in (argument or TORCHREC_AMD_WGRAD_OVERLAP=1), and only
@@ -72,6 +72,15 @@ class TrainPipelineSparseDist:
         self._memcpy_stream = torch.cuda.Stream(device) if use_streams else None
         self._data_dist_stream = torch.cuda.Stream(device) if use_streams else None
         self._requests = {}
+        # explicit-step models: enqueue batch i+1's lookup + pooled all-to-all right behind batch i's embedding backward
+        # (prefetch_lookup=True or TORCHREC_AMD_PREFETCH_LOOKUP=1).  Opt-in: in the one-rank rehearsal at the 8-GPU per-rank
+        # batch it measures 0.5 % SLOWER (1.879 vs 1.871 ms, 1.841 vs 1.832 on another box: the host runs ~70 steps ahead
+        # of the GPU there, so nothing waits for the host at the step boundary, and the all-to-all then overlaps the dense
+        # SGD instead of the bottom MLP); what it can buy on real links — the lookup hidden behind the dense gradient
+        # all-reduce — cannot be measured on a one-GPU box
+        import os
+        self._prefetch = (os.environ.get("TORCHREC_AMD_PREFETCH_LOOKUP", "0") == "1") if prefetch_lookup is None \
+            else bool(prefetch_lookup)
         self._batch_i = None
         self._batch_ip1 = None
         self._batch_ip2 = None
@@ -97,15 +106,34 @@ class TrainPipelineSparseDist:
     def _install(self) -> None:
         root = self._model.module if isinstance(self._model, DistributedModelParallel) else self._model
         ids = {id(s): s for s in self._sharded}
+        self._wrappers: List[_PipelinedEBC] = []
 
         def walk(m):
             for name, child in list(m.named_children()):
                 if id(child) in ids:
-                    setattr(m, name, _PipelinedEBC(child, self))
+                    w = _PipelinedEBC(child, self)
+                    self._wrappers.append(w)
+                    setattr(m, name, w)
                 elif not isinstance(child, _PipelinedEBC):
                     walk(child)
 
         walk(root)
+
+    def _prefetch_next_lookup(self):
+        """Lookup + pooled all-to-all of batch i+1, enqueued behind the last backward launch of batch i (see
+        DLRMTrain.set_between_forward_and_backward).  Returns (its KeyedJaggedTensor, ExplicitLookupStep) or None."""
+        nxt = self._batch_ip1
+        if nxt is None or len(self._wrappers) != 1:
+            return None
+        w = self._wrappers[0]
+        if id(w.sharded) not in self._requests:  # its input dist was not queued (should not happen)
+            return None
+        emb = getattr(w.sharded, "_emb_module", None)
+        if emb is None or getattr(emb, "_cache", None) is not None:
+            return None  # a row cache allows one outstanding training forward; keep those strictly in order
+        with label("## prefetch_next_lookup ##"):
+            step = w.compute_explicit(nxt.sparse_features)
+        return (nxt.sparse_features, step) if step is not None else None
 
     def _to_device(self, batch, non_blocking: bool):
         return batch.to(self._device, non_blocking=non_blocking) if batch is not None else None
@@ -200,7 +228,7 @@ class TrainPipelineSparseDist:
         if explicit:
             # a model that runs its own backward inside forward (models/dlrm.py explicit step) calls this between the two
             # (and labels its own "## forward ##" / "## backward ##" ranges then)
-            root.set_between_forward_and_backward(start_next_input_dist)
+            root.set_between_forward_and_backward(start_next_input_dist, self._prefetch_next_lookup if self._prefetch else None)
         with label("## forward ##"):  # train_pipeline.py:520 (an explicit step nests "## backward ##" inside)
             losses, output = self._model(batch)
         start_next_input_dist()

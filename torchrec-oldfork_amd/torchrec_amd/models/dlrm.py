@@ -365,6 +365,27 @@ class DLRMTrain(nn.Module):
         st = getattr(self, "_flat_dense", None)
         return list(st["params"]) if st is not None else []
 
+    def _start_rest_reduce(self, st) -> None:
+        """Graph-replayed step: folds the autograd / explicit gradients of the non-graphed dense parameters (the replicated
+        tiny tables) into the flat buffer and starts the all-reduce of everything behind the head's slice (bottom MLP +
+        those).  The explicit step calls this as soon as the bottom MLP's backward graph is enqueued — before the fused
+        embedding backward and before the next step's prefetched lookup + pooled all-to-all, so that on the collective
+        stream the (small) dense reduction is queued AHEAD of that all-to-all and overlaps the embedding update."""
+        if st.get("rest_started"):
+            return
+        import torch.distributed as dist
+
+        for q, v in st["extras"]:
+            if q.grad is None:
+                v.zero_()
+            elif q.grad.data_ptr() != v.data_ptr():
+                torch.mul(q.grad, st["scale"], out=v)
+            elif st["scale"] != 1.0:
+                v.mul_(st["scale"])  # autograd accumulated in place (zero_grad(set_to_none=False))
+        if st["world"] > 1:
+            st["works"].append(dist.all_reduce(st["flat"][st["n_head"]:], group=st["pg"], async_op=True))
+        st["rest_started"] = True
+
     def finish_dense_grads(self) -> None:
         """After backward: folds the autograd gradients of the non-graphed dense parameters into the flat
         buffer, all-reduces the rest of it (bottom segment + those), waits, and attaches the slices as
@@ -395,15 +416,8 @@ class DLRMTrain(nn.Module):
             if st["world"] > 1:
                 st["works"].append(dist.all_reduce(st["flat"], group=st["pg"], async_op=True))
         else:
-            for q, v in st["extras"]:
-                if q.grad is None:
-                    v.zero_()
-                elif q.grad.data_ptr() != v.data_ptr():
-                    torch.mul(q.grad, st["scale"], out=v)
-                elif st["scale"] != 1.0:
-                    v.mul_(st["scale"])  # autograd accumulated in place (zero_grad(set_to_none=False))
-            if st["world"] > 1:
-                st["works"].append(dist.all_reduce(st["flat"][st["n_head"]:], group=st["pg"], async_op=True))
+            self._start_rest_reduce(st)
+        st["rest_started"] = False
         for w in st["works"]:
             w.wait()
         st["works"].clear()
@@ -411,10 +425,18 @@ class DLRMTrain(nn.Module):
             q.grad = v
 
     # ---- explicit train step (HIP-graph + flat-gradient mode): forward AND backward without the autograd engine --------
-    def set_between_forward_and_backward(self, fn) -> None:
+    def set_between_forward_and_backward(self, fn, prefetch=None) -> None:
         """A callable the explicit step runs once between its forward and its backward (the train pipeline starts the
-        next batch's input dist there, as it does between `model(batch)` and `loss.backward()` otherwise)."""
+        next batch's input dist there, as it does between `model(batch)` and `loss.backward()` otherwise).
+
+        `prefetch`: a callable the explicit step runs right behind its LAST backward launch (the fused embedding
+        backward): it returns (next batch's KeyedJaggedTensor, its ExplicitLookupStep) or None.  The next step's lookup
+        and pooled all-to-all depend on the tables this step's embedding backward has just updated and on nothing else
+        — not on the dense optimizer, the dense gradient all-reduce or the host's step-boundary work — so they are
+        enqueued here and the GPU has work while the host does that (the step boundary was the largest idle gap of the
+        per-rank step: 98 us of 1.99 ms, profiles/r02_rehearsal_b8192_explicit_gaps.txt)."""
         object.__setattr__(self, "_between", fn)
+        object.__setattr__(self, "_prefetch", prefetch)
 
     def take_backward_done(self) -> bool:
         """True (once) when the latest forward() already ran the backward: the caller must not call loss.backward()."""
@@ -435,8 +457,16 @@ class DLRMTrain(nn.Module):
         if list(inner._feature_names) != list(self.model.sparse_arch.sparse_feature_names):
             return None
         kjt = batch.sparse_features
-        step = (ebc.compute_explicit(kjt) if hasattr(ebc, "sharded")
-                else (ebc.compute_explicit(ebc.input_dist(kjt).wait()) if ebc.explicit_step_supported(kjt.stride()) else None))
+        pre = getattr(self, "_prefetched", None)
+        object.__setattr__(self, "_prefetched", None)
+        if pre is not None and pre[0] is kjt:
+            step = pre[1]  # looked up (and its all-to-all started) at the end of the previous step
+        else:
+            if pre is not None:
+                raise RuntimeError("DLRMTrain: a lookup was prefetched for another batch than the one this step received; the "
+                                   "owner of the pipeline must feed the batches in the order it announced them")
+            step = (ebc.compute_explicit(kjt) if hasattr(ebc, "sharded")
+                    else (ebc.compute_explicit(ebc.input_dist(kjt).wait()) if ebc.explicit_step_supported(kjt.stride()) else None))
         if step is None:
             return None
         B = g_dense.static_inputs[0].shape[0]
@@ -469,7 +499,13 @@ class DLRMTrain(nn.Module):
                 g_dense.bwd_graph.replay()  # its grad_output buffer IS the head's gradient w.r.t. the bottom-MLP output
                 if g_dense.after_backward is not None:
                     g_dense.after_backward()
+                st = getattr(self, "_flat_dense", None)
+                if st is not None and st["fired"] == 2:
+                    self._start_rest_reduce(st)  # ahead of the embedding update and of the next step's all-to-all
                 step.finish_backward()
+            prefetch = getattr(self, "_prefetch", None)
+            if prefetch is not None:
+                object.__setattr__(self, "_prefetched", prefetch())  # (kjt, ExplicitLookupStep) of the NEXT batch, or None
         object.__setattr__(self, "_backward_done", True)
         object.__setattr__(self, "explicit_steps", getattr(self, "explicit_steps", 0) + 1)  # for tests / bench.py's line
         return loss.detach(), (loss.detach(), logits.detach(), batch.labels.detach())
@@ -484,6 +520,7 @@ class DLRMTrain(nn.Module):
                 # only under an owner that asked for it (set_between_forward_and_backward) and will skip loss.backward()
                 out = self._explicit_step(batch, g_dense, g_head)
                 object.__setattr__(self, "_between", None)
+                object.__setattr__(self, "_prefetch", None)
                 if out is not None:
                     return out
             defer, launch = _sort_hooks(self.model.sparse_arch.embedding_bag_collection)
