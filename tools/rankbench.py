@@ -64,9 +64,10 @@ def main():
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--nbatches", type=int, default=8)
     ap.add_argument("--row-cap", type=int, default=0)
+    ap.add_argument("--pooling", type=int, default=1, help="ids per bag (fixed pooling factor)")
     ap.add_argument("--json", default="")
     args = ap.parse_args()
-    W, me, Bg = args.world, args.rank, args.global_batch
+    W, me, Bg, L = args.world, args.rank, args.global_batch, args.pooling
     Bl = Bg // W
     dev = torch.device("cuda", 0)
     rows = [min(r, args.row_cap) if args.row_cap else r for r in CRITEO_1TB_ROWS]
@@ -94,23 +95,23 @@ def main():
     batches = []
     for _ in range(args.nbatches):
         if args.mode == "windows":
-            v = torch.stack([torch.stack([torch.randint(0, rows[g], (Bl,), generator=gen, device=dev) for g in feats])
+            v = torch.stack([torch.stack([torch.randint(0, rows[g], (Bl * L,), generator=gen, device=dev) for g in feats])
                              for _ in range(W)]).reshape(-1)
-            off = torch.arange(W * Fl * Bl + 1, dtype=torch.int64, device=dev)
+            off = torch.arange(W * Fl * Bl + 1, dtype=torch.int64, device=dev) * L
             batches.append((v, off))
         else:
             vals, lens = [], []
             for _ in range(W):
                 for g in feats:
-                    ids = torch.randint(0, rows[g], (Bl,), generator=gen, device=dev)
+                    ids = torch.randint(0, rows[g], (Bl * L,), generator=gen, device=dev)
                     if kind[g] == -1:
                         blk = rw_block_size(rows[g], W)
                         mine = (ids // blk) == me
-                        vals.append(ids[mine] - me * blk)
-                        lens.append(mine.to(torch.int64))
+                        vals.append(ids[mine] - me * blk)  # bag-major order is kept: stable inside a bag
+                        lens.append(mine.view(Bl, L).sum(dim=1).to(torch.int64))
                     else:
                         vals.append(ids)
-                        lens.append(torch.ones(Bl, dtype=torch.int64, device=dev))
+                        lens.append(torch.full((Bl,), L, dtype=torch.int64, device=dev))
             lens = torch.cat(lens)
             off = torch.zeros(lens.numel() + 1, dtype=torch.int64, device=dev)
             off[1:] = torch.cumsum(lens, 0)
@@ -181,8 +182,8 @@ def main():
     n_rw_all = sum(1 for k in kind if k == -1)
     if n_rw_all:
         rw_tabs = [t for t, k in enumerate(kind) if k == -1]
-        ids = torch.cat([torch.randint(0, rows[t], (Bl,), generator=gen, device=dev) for t in rw_tabs])
-        lens = torch.ones(n_rw_all * Bl, dtype=torch.int32, device=dev)
+        ids = torch.cat([torch.randint(0, rows[t], (Bl * L,), generator=gen, device=dev) for t in rw_tabs])
+        lens = torch.full((n_rw_all * Bl,), L, dtype=torch.int32, device=dev)
         blocks = torch.tensor([rw_block_size(rows[t], W) for t in rw_tabs], dtype=torch.int64, device=dev)
 
         def bucketize(i):
@@ -194,14 +195,15 @@ def main():
     # ---- algorithmic bytes (SURVEY.md §8d terms, per step on this rank) -------------------------------------------
     N = sum(n_ids) / len(n_ids)
     bags = W * Fl * Bl
-    local_rw = n_rw * Bg / W  # ids of row-wise features that fall into this rank's window (expected)
-    rows_read = n_tw * Bg + local_rw
-    zero_rows = n_rw * Bg - local_rw  # output rows written as zeros (foreign / empty bags)
-    fwd_useful = rows_read * D * 4 + N * 8 + bags * 8 + rows_read * D * 4
+    local_rw = n_rw * Bg * L / W  # ids of row-wise features that fall into this rank's window (expected)
+    rows_read = n_tw * Bg * L + local_rw
+    nonzero_out = n_tw * Bg + n_rw * Bg * (1.0 - (1.0 - 1.0 / W) ** L)  # bags with at least one local id
+    zero_rows = (n_tw + n_rw) * Bg - nonzero_out  # output rows written as zeros (bags without a local id)
+    fwd_useful = rows_read * D * 4 + N * 8 + bags * 8 + nonzero_out * D * 4
     fwd_zero_write = zero_rows * D * 4
-    bwd_useful = rows_read * D * 4 + N * 8 + bags * 8 + U * 2 * D * 4
+    bwd_useful = rows_read * D * 4 + N * 8 + bags * 8 + U * 2 * D * 4  # one gradient row read per local id
     out = {
-        "world": W, "rank": me, "mode": args.mode, "global_batch": Bg, "local_batch": Bl,
+        "world": W, "rank": me, "mode": args.mode, "global_batch": Bg, "local_batch": Bl, "pooling_factor": L,
         "held": {"table_wise": n_tw, "row_wise_shards": n_rw, "replicated": n_dp, "GiB": round(held_gib, 2)},
         "ids_per_step": N, "bags_per_step": bags, "distinct_rows_updated_per_step": U,
         "us_per_step": {k: round(v, 1) for k, v in us.items()},
