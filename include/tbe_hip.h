@@ -419,6 +419,35 @@ size_t tbe_weighted_colsum_workspace_bytes(int64_t B, int32_t N);
 int tbe_weighted_colsum_f32(const float* x, const float* w, int64_t B, int32_t N, float* out,
                             void* workspace, size_t workspace_bytes, void* stream);
 
+/* The first stages of the two above alone: the column sums of the row blocks stay in `partial`
+ * [tbe_colsum_row_blocks(B, N)][N] (16-B aligned, B > 0) for ONE later tbe_multi_chunk_sum_f32 over every layer of a
+ * captured backward. */
+int64_t tbe_colsum_row_blocks(int64_t B, int32_t N);
+int tbe_relu_backward_bias_partials_f32(const float* grad_out, const float* act, int64_t B, int32_t N,
+                                        float* grad_in, float* partial, size_t partial_bytes, void* stream);
+int tbe_weighted_colsum_partials_f32(const float* x, const float* w, int64_t B, int32_t N, float* partial,
+                                     size_t partial_bytes, void* stream);
+
+/* dst[off_s + i] = scale * sum_{c < chunks_s} src_s[c * numel_s + i] for every segment s of `seg_table` — device int64
+ * [nseg][4] = {src address, chunks, numel, dst element offset}; chunk order fixed (deterministic); chunks = 0 writes
+ * zeros.  max_numel = the largest numel.  Finishes, in one launch, the split-K weight gradients (chunks = batch slices of
+ * the batched GEMM), the bias gradients (chunks = row blocks of the kernels above) and the already complete gradients
+ * (chunks = 1) of the dense MLPs' backward, scaled by 1 / world size, into the flat gradient buffer that is all-reduced —
+ * what the reference leaves to per-parameter autograd kernels + DistributedDataParallel's bucket copies
+ * (torchrec/distributed/model_parallel.py:101-111). */
+int tbe_multi_chunk_sum_f32(const int64_t* seg_table, int32_t nseg, int64_t max_numel, float* dst, float scale,
+                            void* stream);
+
+/* nn.BCEWithLogitsLoss (mean) forward + gradient in one launch — the loss of the reference's train wrapper
+ * (examples/dlrm/modules/dlrm_train.py):  loss = mean_i [max(x_i, 0) - x_i y_i + log1p(exp(-|x_i|))],
+ * dlogits_i = (sigmoid(x_i) - y_i) / B  (dlogits may be NULL).  labels: float32 (label_elem_size 4) or int64 (8).
+ * Deterministic (fixed block ranges, block partials added in index order by the last block).  workspace:
+ * tbe_bce_with_logits_workspace_bytes() bytes, 16-B aligned, ZEROED ONCE by the caller before its first use and then
+ * reusable launch after launch (the kernel resets its ticket). */
+size_t tbe_bce_with_logits_workspace_bytes(void);
+int tbe_bce_with_logits_f32(const float* logits, const void* labels, int32_t label_elem_size, int64_t B, float* loss,
+                            float* dlogits, void* workspace, size_t workspace_bytes, void* stream);
+
 /* torch.ops.fbgemm.jagged_2d_to_dense (examples/bert4rec/models/bert4rec.py:394-400):
  * values [N, D] + offsets [B+1] -> dense [B, max_L, D], zero padded / truncated. */
 int tbe_jagged_2d_to_dense_f32(const float* values, const int64_t* offsets, int32_t B,

@@ -142,3 +142,71 @@ def test_wgrad_on_side_stream_matches_inline():
         assert not _WgradOverlap.on and not _WgradOverlap.pending
         for a, b in zip(want, got):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,dtype", [(8192, torch.int64), (65536, torch.int64), (65536, torch.float32), (1, torch.float32),
+                                     (3001, torch.int64), (1 << 20, torch.float32)])
+def test_fused_bce_with_logits_matches_torch(B, dtype):
+    """csrc/mlp_epilogue.hip bce_with_logits_kernel: nn.BCEWithLogitsLoss (mean; the reference's train wrapper,
+    examples/dlrm/modules/dlrm_train.py) and its gradient in ONE launch, labels int64 or float; deterministic."""
+    from torchrec_amd.models.dlrm import bce_with_logits_mean
+
+    torch.manual_seed(B)
+    x = (torch.randn(B, device="cuda") * 6).requires_grad_()
+    y = torch.randint(0, 2, (B,), device="cuda").to(dtype)
+    loss_fn = torch.nn.BCEWithLogitsLoss()
+    loss = bce_with_logits_mean(loss_fn, x, y)
+    (3.0 * loss).backward()
+    x2 = x.detach().clone().requires_grad_()
+    ref = loss_fn(x2, y.float())
+    (3.0 * ref).backward()
+    torch.testing.assert_close(loss, ref, rtol=2e-6, atol=1e-7)
+    torch.testing.assert_close(x.grad, x2.grad, rtol=2e-6, atol=1e-9)
+    again = bce_with_logits_mean(loss_fn, x.detach(), y)
+    assert torch.equal(again, loss.detach())  # fixed summation order
+    # everything the fused kernel does not cover goes to torch's
+    w = torch.nn.BCEWithLogitsLoss(pos_weight=torch.tensor(2.0, device="cuda"))
+    torch.testing.assert_close(bce_with_logits_mean(w, x.detach(), y), w(x.detach(), y.float()))
+
+
+def test_multi_chunk_sum_finishes_every_gradient_in_one_launch():
+    """csrc/mlp_epilogue.hip multi_chunk_sum_kernel: split-K chunk sums, row-block bias sums, complete gradients and
+    gradient-less parameters (chunks 32 / 128 / 1 / 0; numel multiples of 4 and not; misaligned destinations) summed in
+    fixed order, scaled, into one flat buffer."""
+    import torchrec_amd.distributed._device_ops  # noqa: F401
+
+    torch.manual_seed(4)
+    shapes = [(32, 1024 * 479), (128, 256), (1, 512 * 13), (0, 64), (7, 1), (5, 1023), (1, 3), (256, 128)]
+    srcs = [torch.randn(max(c, 1), n, device="cuda") for c, n in shapes]
+    total = sum(n for _, n in shapes)
+    dst = torch.full((total + 8,), 7.0, device="cuda")[4:4 + total]  # 16-B aligned start, unaligned segments inside
+    rows, off = [], 0
+    for (c, n), s in zip(shapes, srcs):
+        rows.append([s.data_ptr(), c, n, off])
+        off += n
+    table = torch.tensor(rows, dtype=torch.int64, device="cuda")
+    torch.ops.tbe_hip.multi_chunk_sum(table, len(rows), max(n for _, n in shapes), dst, 0.5)
+    off = 0
+    for (c, n), s in zip(shapes, srcs):
+        ref = (s[:c].double().sum(0) * 0.5).float() if c else torch.zeros(n, device="cuda")
+        torch.testing.assert_close(dst[off:off + n], ref, rtol=2e-5, atol=2e-5)
+        off += n
+    first = dst.clone()
+    torch.ops.tbe_hip.multi_chunk_sum(table, len(rows), max(n for _, n in shapes), dst, 0.5)
+    assert torch.equal(first, dst)
+
+
+@pytest.mark.parametrize("B,N", [(8192, 1024), (8192, 128), (65536, 256), (1000, 52)])
+def test_row_block_partials_sum_to_the_one_pass_results(B, N):
+    import torchrec_amd.distributed._device_ops  # noqa: F401
+
+    torch.manual_seed(2)
+    gy = torch.randn(B, N, device="cuda")
+    act = torch.relu(torch.randn(B, N, device="cuda"))
+    gx, gb = torch.ops.tbe_hip.relu_backward_bias_grad(gy, act)
+    gx2, part = torch.ops.tbe_hip.relu_backward_bias_partials(gy, act)
+    assert torch.equal(gx, gx2) and part.shape[1] == N
+    torch.testing.assert_close(part.double().sum(0).float(), gb, rtol=1e-5, atol=1e-4)
+    w = torch.randn(B, device="cuda")
+    torch.testing.assert_close(torch.ops.tbe_hip.weighted_colsum_partials(gy, w).double().sum(0).float(),
+                               torch.ops.tbe_hip.weighted_colsum(gy, w), rtol=1e-5, atol=1e-4)

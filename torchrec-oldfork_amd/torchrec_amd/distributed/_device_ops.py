@@ -18,6 +18,10 @@ _def.define("a2a_pooled_pack(Tensor grad, Tensor dim_sum_per_rank, bool vec, flo
 _def.define("relu_backward_bias_grad(Tensor grad_out, Tensor act) -> (Tensor, Tensor)")
 _def.define("weighted_colsum(Tensor x, Tensor w) -> Tensor")
 _def.define("copy_rows(Tensor src, Tensor rows) -> Tensor")
+_def.define("relu_backward_bias_partials(Tensor grad_out, Tensor act) -> (Tensor, Tensor)")
+_def.define("weighted_colsum_partials(Tensor x, Tensor w) -> Tensor")
+_def.define("multi_chunk_sum(Tensor seg_table, int nseg, int max_numel, Tensor(a!) dst, float scale) -> Tensor(a!)")
+_def.define("bce_with_logits(Tensor logits, Tensor labels) -> (Tensor, Tensor)")
 _impl = torch.library.Library("tbe_hip", "IMPL", "CUDA")
 
 
@@ -71,6 +75,77 @@ def _relu_backward_bias_grad(grad_out, act):
         check(lib.tbe_relu_backward_bias_grad_f32(ptr(grad_out), ptr(act), B, N, ptr(gx), ptr(gb), ptr(ws), ws.numel(),
                                                   stream_ptr(dev)), "tbe_relu_backward_bias_grad_f32")
     return gx, gb
+
+
+def _relu_backward_bias_partials(grad_out, act):
+    """(grad_out * (act > 0), column sums of its row blocks [row blocks, N]) — the first stage of relu_backward_bias_grad
+    alone; `multi_chunk_sum` finishes every layer's bias gradient in one launch (csrc/mlp_epilogue.hip)."""
+    dev = require_gpu(grad_out, act)
+    if grad_out.dim() != 2 or grad_out.shape != act.shape or grad_out.dtype != torch.float32 or act.dtype != torch.float32:
+        raise RuntimeError(f"relu_backward_bias_partials: need two float32 [B, N] tensors of one shape, got "
+                           f"{tuple(grad_out.shape)} and {tuple(act.shape)}")
+    grad_out, act = grad_out.contiguous(), act.contiguous()
+    B, N = grad_out.shape
+    lib = _lib.load()
+    gx = torch.empty_like(grad_out)
+    partial = torch.empty((lib.tbe_colsum_row_blocks(B, N), N), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.tbe_relu_backward_bias_partials_f32(ptr(grad_out), ptr(act), B, N, ptr(gx), ptr(partial),
+                                                      partial.numel() * 4, stream_ptr(dev)), "tbe_relu_backward_bias_partials_f32")
+    return gx, partial
+
+
+def _weighted_colsum_partials(x, w):
+    """Row-block partials [row blocks, N] of out[c] = sum_b w[b] * x[b, c] (first stage of weighted_colsum)."""
+    dev = require_gpu(x, w)
+    if x.dim() != 2 or w.numel() != x.shape[0] or x.dtype != torch.float32 or w.dtype != torch.float32:
+        raise RuntimeError(f"weighted_colsum_partials: need float32 x [B, N] and w [B], got {tuple(x.shape)} and {tuple(w.shape)}")
+    x, w = x.contiguous(), w.contiguous().view(-1)
+    B, N = x.shape
+    lib = _lib.load()
+    partial = torch.empty((lib.tbe_colsum_row_blocks(B, N), N), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.tbe_weighted_colsum_partials_f32(ptr(x), ptr(w), B, N, ptr(partial), partial.numel() * 4, stream_ptr(dev)),
+              "tbe_weighted_colsum_partials_f32")
+    return partial
+
+
+def _multi_chunk_sum(seg_table, nseg, max_numel, dst, scale):
+    """dst[off_s + i] = scale * sum_c src_s[c, i] for every segment of `seg_table` (device int64 [nseg, 4]: src address,
+    chunks, numel, dst element offset) in one launch; the caller keeps the sources alive."""
+    dev = require_gpu(seg_table, dst)
+    if seg_table.dtype != torch.int64 or not seg_table.is_contiguous() or seg_table.numel() != 4 * nseg:
+        raise RuntimeError("multi_chunk_sum: seg_table must be a contiguous int64 [nseg, 4] device tensor")
+    if dst.dtype != torch.float32 or not dst.is_contiguous():
+        raise RuntimeError("multi_chunk_sum: dst must be a contiguous float32 tensor")
+    with torch.cuda.device(dev):
+        check(_lib.load().tbe_multi_chunk_sum_f32(ptr(seg_table), nseg, max_numel, ptr(dst), scale, stream_ptr(dev)),
+              "tbe_multi_chunk_sum_f32")
+    return dst
+
+
+_bce_ws = {}
+
+
+def _bce_with_logits(logits, labels):
+    """(mean BCE-with-logits loss [scalar], d loss / d logits [B]) in one launch; labels float32 or int64."""
+    dev = require_gpu(logits, labels)
+    if logits.dim() != 1 or labels.shape != logits.shape or logits.dtype != torch.float32:
+        raise RuntimeError(f"bce_with_logits: need float32 logits [B] and labels [B], got {tuple(logits.shape)} / {tuple(labels.shape)}")
+    if labels.dtype not in (torch.float32, torch.int64):
+        labels = labels.float()
+    logits, labels = logits.contiguous(), labels.contiguous()
+    lib = _lib.load()
+    key = (dev, stream_ptr(dev))  # one workspace per stream: two streams must not share block partials / the ticket
+    ws = _bce_ws.get(key)
+    if ws is None:  # [block partials | ticket]: zeroed once, the kernel resets its ticket
+        ws = _bce_ws[key] = torch.zeros(lib.tbe_bce_with_logits_workspace_bytes(), dtype=torch.uint8, device=dev)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    dlogits = torch.empty_like(logits)
+    with torch.cuda.device(dev):
+        check(lib.tbe_bce_with_logits_f32(ptr(logits), ptr(labels), labels.element_size(), logits.numel(), ptr(loss),
+                                          ptr(dlogits), ptr(ws), ws.numel(), stream_ptr(dev)), "tbe_bce_with_logits_f32")
+    return loss, dlogits
 
 
 def _simple_unpack(recv, dims, B_local, D_total, vec, scale):
@@ -131,6 +206,10 @@ def _pack(grad, feat_out_col, feat_src, feat_slab_col, slab_offset, slab_stride,
 _impl.impl("relu_backward_bias_grad", _relu_backward_bias_grad)
 _impl.impl("weighted_colsum", _weighted_colsum)
 _impl.impl("copy_rows", _copy_rows)
+_impl.impl("relu_backward_bias_partials", _relu_backward_bias_partials)
+_impl.impl("weighted_colsum_partials", _weighted_colsum_partials)
+_impl.impl("multi_chunk_sum", _multi_chunk_sum)
+_impl.impl("bce_with_logits", _bce_with_logits)
 _impl.impl("pooled_exchange_unpack", _unpack)
 _impl.impl("pooled_exchange_unpack_into", _unpack_into)
 _impl.impl("pooled_exchange_pack", _pack)

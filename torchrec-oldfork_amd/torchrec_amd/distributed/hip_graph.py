@@ -134,21 +134,50 @@ class GraphedSegment(nn.Module):
         if param_grad_sinks is not None and len(param_grad_sinks) != len(self._params):
             raise ValueError("one gradient sink per parameter")
 
-        def write_sinks(pg_) -> None:
+        def write_sinks(pg_, partials=None) -> None:
+            """pg_[j]: complete gradient of parameter j or None; partials[j] (optional): [chunks, *shape] whose sum over
+            dim 0 is the gradient (split-K slices, row-block sums: modules/mlp.py _DeferredWgrad)."""
             sinks = list(param_grad_sinks)
+            partials = partials if partials is not None else [None] * len(sinks)
             consecutive = all(s_.is_contiguous() for s_ in sinks) and all(
                 sinks[i + 1].data_ptr() == sinks[i].data_ptr() + sinks[i].numel() * sinks[i].element_size()
                 for i in range(len(sinks) - 1))
-            if consecutive and sinks and all(g is not None for g in pg_):
-                # the sinks are consecutive slices of ONE flat buffer: one batched copy + one scale instead of
-                # a kernel per parameter (16 launches of ~5 us per step at the 8-GPU per-rank batch)
+            fp32 = all(s_.dtype == torch.float32 for s_ in sinks) and all(
+                (g is None or g.dtype == torch.float32) for g in list(pg_) + list(partials))
+            if consecutive and sinks and fp32 and sinks[0].is_cuda:
+                # the sinks are consecutive slices of ONE flat buffer: ONE launch sums every parameter's chunks (1 for a
+                # complete gradient, 0 = no gradient: zeros) and writes the scaled result — instead of a reduce kernel
+                # per split-K layer, a column-sum launch per bias, a cat and a mul (csrc/mlp_epilogue.hip)
+                from . import _device_ops  # noqa: F401  (registers torch.ops.tbe_hip.*)
                 total = sum(s_.numel() for s_ in sinks)
                 flat_slice = torch.as_strided(sinks[0], (total,), (1,), sinks[0].storage_offset())
-                torch.cat([g.reshape(-1) for g in pg_], out=flat_slice)
-                if sink_scale != 1.0:
-                    flat_slice.mul_(sink_scale)
+                rows, keep, off = [], [], 0
+                for g, part, sink in zip(pg_, partials, sinks):
+                    n = sink.numel()
+                    if part is not None and g is not None:  # a parameter used twice: fold the complete part in
+                        part = torch.cat([part.reshape(part.shape[0], -1), g.reshape(1, -1)])
+                    if part is not None:
+                        src = part.contiguous().view(part.shape[0], -1)
+                        if src.shape[1] != n:
+                            raise RuntimeError("capture_backward: partial gradient does not match its parameter")
+                        rows.append([src.data_ptr(), src.shape[0], n, off])
+                        keep.append(src)
+                    elif g is not None:
+                        src = g.contiguous().view(-1)
+                        rows.append([src.data_ptr(), 1, n, off])
+                        keep.append(src)
+                    else:
+                        rows.append([flat_slice.data_ptr(), 0, n, off])
+                    off += n
+                # the segment table lives in the graph's pool (a static address the captured launch reads); its contents —
+                # addresses that are final only now — are uploaded ONCE, right after the capture has ended (below)
+                table = torch.empty((len(rows), 4), dtype=torch.int64, device=sinks[0].device)
+                torch.ops.tbe_hip.multi_chunk_sum(table, len(rows), max(r[2] for r in rows), flat_slice, float(sink_scale))
+                self._sink_tables.append((table, rows, keep))
             else:
-                for g, sink in zip(pg_, sinks):
+                for g, part, sink in zip(pg_, partials, sinks):
+                    if part is not None:
+                        g = part.sum(dim=0).view_as(sink) if g is None else g + part.sum(dim=0).view_as(sink)
                     if g is None:
                         sink.zero_()
                     else:
@@ -157,29 +186,53 @@ class GraphedSegment(nn.Module):
 
         self.bwd_graph = torch.cuda.CUDAGraph()
         self.bwd_graph2: Optional[torch.cuda.CUDAGraph] = None
+        self._sink_tables = []  # (device table inside the graph pool, its rows, the source tensors kept alive)
         self._stream.synchronize()
         stash = []
+        with_partials = bool(defer_wgrad and param_grad_sinks is not None)
         with torch.cuda.graph(self.bwd_graph, pool=self._pool, stream=self._stream, capture_error_mode="thread_local"):
             _DeferredWgrad.pending = [] if defer_wgrad else None
+            _DeferredWgrad.partials_ok = with_partials
             try:
                 grads = list(torch.autograd.grad(need, targets, [g for g in self.static_grad_outputs if g is not None],
                                                  allow_unused=True))
             finally:
                 stash, _DeferredWgrad.pending = (_DeferredWgrad.pending or []), None
+                _DeferredWgrad.partials_ok = False
             if param_grad_sinks is not None and not stash:
                 write_sinks(grads[n_in:])
         if stash:
             index = {id(p): n_in + j for j, p in enumerate(self._params)}
+            partials = [None] * len(grads)
             self.bwd_graph2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.bwd_graph2, pool=self._pool, stream=self._stream, capture_error_mode="thread_local"), \
                     torch.no_grad():  # X of a layer is an activation inside the forward's autograd graph
-                for w, gy, x, c in stash:
-                    gw = _DeferredWgrad.compute(gy, x, c)
-                    k = index[id(w)]
-                    grads[k] = gw if grads[k] is None else grads[k] + gw
+                for entry in stash:
+                    kind, prm = entry[0], entry[1]
+                    k = index[id(prm)]
+                    if kind == "w":
+                        _, _, gy, x, c = entry
+                        part = _DeferredWgrad.compute_partials(gy, x, c) if with_partials else None
+                        gw = None if with_partials else _DeferredWgrad.compute(gy, x, c)
+                    else:
+                        part, gw = entry[2], None
+                    if part is not None:
+                        part = part.reshape(part.shape[0], -1)
+                        partials[k] = part if partials[k] is None else torch.cat([partials[k], part])
+                    else:
+                        grads[k] = gw if grads[k] is None else grads[k] + gw
                 if param_grad_sinks is not None:
-                    write_sinks(grads[n_in:])
+                    write_sinks(grads[n_in:], partials[n_in:])
+                else:
+                    for k, part in enumerate(partials):
+                        if part is not None:  # not reached today (partials are only stashed with sinks); kept consistent
+                            full = part.sum(dim=0).view_as(self._params[k - n_in])
+                            grads[k] = full if grads[k] is None else grads[k] + full
             self._wgrad_stash = stash  # dY / X of the first graph stay allocated: the second graph reads them
+        for table, rows, _ in self._sink_tables:  # outside every capture: fill the segment tables the graphs read
+            table.copy_(torch.tensor(rows, dtype=torch.int64))
+        if self._sink_tables:
+            torch.cuda.synchronize(self._sink_tables[0][0].device)
         it = iter(grads)
         self.static_grad_inputs = [next(it) if x.requires_grad else None for x in self.static_inputs]
         self.static_grad_inputs += list(it)  # parameter gradients, in self._params order

@@ -215,9 +215,39 @@ class DLRM(nn.Module):
         return self.over_arch(concatenated)
 
 
+# nn.BCEWithLogitsLoss (mean) as ONE kernel for loss + gradient (csrc/mlp_epilogue.hip bce_with_logits_kernel) instead of 8
+# element-wise / reduce kernels forward and 5 backward; TORCHREC_AMD_FUSED_BCE=0 keeps torch's
+_FUSED_BCE = os.environ.get("TORCHREC_AMD_FUSED_BCE", "1") != "0"
+
+
+class _FusedBCEWithLogits(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels):
+        from ..distributed import _device_ops  # noqa: F401  (registers torch.ops.tbe_hip.*)
+
+        loss, dlogits = torch.ops.tbe_hip.bce_with_logits(logits, labels)
+        ctx.save_for_backward(dlogits)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (dlogits,) = ctx.saved_tensors
+        return dlogits * grad_out, None
+
+
+def bce_with_logits_mean(loss_fn: nn.Module, logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    """`loss_fn(logits, labels.float())` for the train wrapper's nn.BCEWithLogitsLoss (examples/dlrm/modules/dlrm_train.py);
+    on a HIP device, for the plain mean-reduced loss over float32 logits [B], one fused kernel (labels int64 or float)."""
+    if (_FUSED_BCE and logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 1 and labels.shape == logits.shape
+            and type(loss_fn) is nn.BCEWithLogitsLoss and loss_fn.reduction == "mean" and loss_fn.weight is None
+            and loss_fn.pos_weight is None and logits.numel() > 0 and labels.dtype in (torch.float32, torch.int64)):
+        return _FusedBCEWithLogits.apply(logits, labels)
+    return loss_fn(logits, labels.float())
+
+
 class _Head(nn.Module):
     """interaction + over arch + loss as ONE static-shape segment (inputs: bottom-MLP output, pooled
-    embeddings [B, F, D], labels as float) -> (loss, logits)."""
+    embeddings [B, F, D], labels as they come: int64 or float) -> (loss, logits)."""
 
     def __init__(self, inter_arch: nn.Module, over_arch: nn.Module, loss_fn: nn.Module) -> None:
         super().__init__()
@@ -225,7 +255,7 @@ class _Head(nn.Module):
 
     def forward(self, embedded_dense: torch.Tensor, embedded_sparse: torch.Tensor, labels: torch.Tensor):
         logits = self.over_arch(self.inter_arch(dense_features=embedded_dense, sparse_features=embedded_sparse)).squeeze(-1)
-        return self.loss_fn(logits, labels), logits
+        return bce_with_logits_mean(self.loss_fn, logits, labels), logits
 
 
 class DLRMTrain(nn.Module):
@@ -287,7 +317,7 @@ class DLRMTrain(nn.Module):
         g_head = GraphedSegment(
             head, [g_dense.static_outputs[0].detach().requires_grad_(True),
                    torch.randn(B, F, D, device=dev).requires_grad_(True),
-                   torch.randint(0, 2, (B,), device=dev).float()],
+                   torch.randint(0, 2, (B,), device=dev)],  # int64, as the data loader delivers them
             input_buffers=[g_dense.static_outputs[0], None, None], pool=g_dense._pool)
         head_sinks = dense_sinks = None
         scale = 1.0
@@ -340,7 +370,8 @@ class DLRMTrain(nn.Module):
         # started the embedding-gradient all-to-all (modules/mlp.py _DeferredWgrad)
         g_head.capture_backward(param_grad_sinks=head_sinks, sink_scale=scale, defer_wgrad=flat_grads and _DEFER_WGRAD)
         # the head's gradient w.r.t. the bottom-MLP output doubles as the bottom segment's grad_output buffer
-        g_dense.capture_backward([g_head.static_grad_inputs[0]], param_grad_sinks=dense_sinks, sink_scale=scale)
+        g_dense.capture_backward([g_head.static_grad_inputs[0]], param_grad_sinks=dense_sinks, sink_scale=scale,
+                                 defer_wgrad=flat_grads and _DEFER_WGRAD)
         object.__setattr__(self, "_graphs", (B, g_dense, g_head))  # not sub-modules: state_dict keys unchanged
         # the explicit step fills d(loss) = 1 into the NEW head segment's grad-output buffer (zeros after capture)
         object.__setattr__(self, "_loss_grad_ready", False)
@@ -478,7 +509,7 @@ class DLRMTrain(nn.Module):
             pooled = step.finish()  # written into the head segment's static input by the collection
             if pooled.data_ptr() != g_head.static_inputs[1].data_ptr():
                 g_head.static_inputs[1].copy_(pooled.view_as(g_head.static_inputs[1]))
-            g_head.static_inputs[2].copy_(batch.labels)  # int64 -> float32
+            g_head.static_inputs[2].copy_(batch.labels)
             g_head.fwd_graph.replay()
             loss, logits = g_head.static_outputs[0], g_head.static_outputs[1]
             between = getattr(self, "_between", None)
@@ -497,6 +528,8 @@ class DLRMTrain(nn.Module):
                 if g_head.after_backward is not None:
                     g_head.after_backward()  # all-reduce of the head's slice of the flat gradient
                 g_dense.bwd_graph.replay()  # its grad_output buffer IS the head's gradient w.r.t. the bottom-MLP output
+                if getattr(g_dense, "bwd_graph2", None) is not None:
+                    g_dense.bwd_graph2.replay()  # its weight / bias gradients, finished into the flat buffer
                 if g_dense.after_backward is not None:
                     g_dense.after_backward()
                 st = getattr(self, "_flat_dense", None)
@@ -532,8 +565,8 @@ class DLRMTrain(nn.Module):
             if launch is not None:
                 launch()  # beside the head segment (interaction + over arch), after the lookup and the exchange
             object.__setattr__(self, "_loss_grad_ready", False)  # autograd writes whatever d(loss) the caller backpropagates
-            loss, logits = g_head(embedded_dense, embedded_sparse, batch.labels.float())
+            loss, logits = g_head(embedded_dense, embedded_sparse, batch.labels.to(g_head.static_inputs[2].dtype))
             return loss, (loss.detach(), logits.detach(), batch.labels.detach())
         logits = self.model(batch.dense_features, batch.sparse_features).squeeze(-1)
-        loss = self.loss_fn(logits, batch.labels.float())
+        loss = bce_with_logits_mean(self.loss_fn, logits, batch.labels)
         return loss, (loss.detach(), logits.detach(), batch.labels.detach())

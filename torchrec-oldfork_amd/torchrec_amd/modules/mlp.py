@@ -58,9 +58,14 @@ class _DeferredWgrad:
     True)): the capture of the input-gradient chain ends first, and the weight-gradient GEMMs are captured into a second
     graph that the owner replays AFTER it has started the embedding-gradient all-to-all — dW is needed by nobody until the
     optimizer, the all-to-all by the embedding backward (models/dlrm.py explicit step).  `pending` is a list while such a
-    capture is running, else None; entries are (weight parameter, dY, X, split-K chunks)."""
+    capture is running, else None; entries are ("w", weight parameter, dY, X, split-K chunks) or — with `partials_ok`, i.e.
+    when the segment's parameter gradients go into a flat buffer (param_grad_sinks) — ("p", parameter, partial sums
+    [chunks, *parameter shape]): bias gradients as the row-block sums of the ReLU-backward kernel, the one-output layer's
+    weight gradient as the row-block sums of its column-sum kernel.  The capture then finishes EVERY gradient of the segment
+    — split-K chunk sums, row-block sums, complete gradients — with one `multi_chunk_sum` launch into the flat buffer."""
 
     pending: Optional[list] = None
+    partials_ok: bool = False
 
     @classmethod
     def compute(cls, gy: torch.Tensor, x: torch.Tensor, c: int) -> torch.Tensor:
@@ -68,6 +73,18 @@ class _DeferredWgrad:
         if c > 1 and B % c == 0:
             return torch.bmm(gy.view(c, B // c, -1).transpose(1, 2), x.view(c, B // c, -1)).sum(dim=0)
         return gy.t() @ x
+
+    @classmethod
+    def compute_partials(cls, gy: torch.Tensor, x: torch.Tensor, c: int) -> torch.Tensor:
+        """[chunks, out, in] whose sum over dim 0 is dY^T X (the batched GEMM of `compute` without its reduction)."""
+        B = x.shape[0]
+        if c > 1 and B % c == 0:
+            return torch.bmm(gy.view(c, B // c, -1).transpose(1, 2), x.view(c, B // c, -1))
+        return (gy.t() @ x).unsqueeze(0)
+
+    @classmethod
+    def stashing(cls, t: torch.Tensor) -> bool:
+        return cls.pending is not None and t.is_cuda and torch.cuda.is_current_stream_capturing()
 
 
 class _LinearSplitKWgrad(torch.autograd.Function):
@@ -85,6 +102,7 @@ class _LinearSplitKWgrad(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.fuse_relu = fuse_relu
         ctx.weight_param = weight if (weight.is_leaf and weight.requires_grad) else None
+        ctx.bias_param = bias if (bias is not None and bias.is_leaf and bias.requires_grad) else None
         if fuse_relu:
             # bias + ReLU in the GEMM epilogue (hipBLASLt): no separate activation kernel
             out = torch._addmm_activation(bias, x, weight.t(), use_gelu=False)
@@ -96,12 +114,20 @@ class _LinearSplitKWgrad(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         gb = None
+        gb_deferred = False
         if ctx.fuse_relu:
             x, weight, out = ctx.saved_tensors
             if ctx.has_bias and gy.dtype == torch.float32 and out.shape[1] % 4 == 0:
                 # ReLU backward + bias gradient in one pass over [B, out] (csrc/mlp_epilogue.hip)
                 from ..distributed import _device_ops  # noqa: F401  (registers torch.ops.tbe_hip.*)
-                gy, gb = torch.ops.tbe_hip.relu_backward_bias_grad(gy, out)
+                if (_DeferredWgrad.partials_ok and ctx.bias_param is not None and ctx.needs_input_grad[2]
+                        and _DeferredWgrad.stashing(gy)):
+                    # the row-block sums are finished later, together with every other gradient of the segment
+                    gy, part = torch.ops.tbe_hip.relu_backward_bias_partials(gy, out)
+                    _DeferredWgrad.pending.append(("p", ctx.bias_param, part))
+                    gb_deferred = True
+                else:
+                    gy, gb = torch.ops.tbe_hip.relu_backward_bias_grad(gy, out)
             else:
                 gy = torch.ops.aten.threshold_backward(gy.contiguous(), out, 0.0)
         else:
@@ -123,9 +149,8 @@ class _LinearSplitKWgrad(torch.autograd.Function):
             return _DeferredWgrad.compute(gy, x, c)
 
         w = ctx.weight_param
-        if (w is not None and ctx.needs_input_grad[1] and _DeferredWgrad.pending is not None and gy.is_cuda
-                and torch.cuda.is_current_stream_capturing()):
-            _DeferredWgrad.pending.append((w, gy, x, c))  # captured later, into the segment's second backward graph
+        if w is not None and ctx.needs_input_grad[1] and _DeferredWgrad.stashing(gy):
+            _DeferredWgrad.pending.append(("w", w, gy, x, c))  # captured later, into the segment's second backward graph
             gw = None
         elif w is not None and ctx.needs_input_grad[1] and _WgradOverlap.active_for(gy):
             side, cur = _WgradOverlap.stream, torch.cuda.current_stream()
@@ -147,7 +172,7 @@ class _LinearSplitKWgrad(torch.autograd.Function):
             gw = None
         else:
             gw = wgrad()
-        if gb is None and ctx.has_bias:
+        if gb is None and ctx.has_bias and not gb_deferred:
             gb = gy.sum(dim=0)
         return gx, gw, gb, None, None
 
@@ -161,6 +186,7 @@ class _LinearOneOutput(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.weight_param = weight if (weight.is_leaf and weight.requires_grad) else None
         return torch.nn.functional.linear(x, weight, bias)
 
     @staticmethod
@@ -170,7 +196,12 @@ class _LinearOneOutput(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         gy = gy.contiguous()
         gx = gy @ weight if ctx.needs_input_grad[0] else None
-        gw = torch.ops.tbe_hip.weighted_colsum(x, gy.view(-1)).view(1, -1)
+        if _DeferredWgrad.partials_ok and ctx.weight_param is not None and _DeferredWgrad.stashing(gy):
+            part = torch.ops.tbe_hip.weighted_colsum_partials(x, gy.view(-1))  # [row blocks, in]
+            _DeferredWgrad.pending.append(("p", ctx.weight_param, part.view(part.shape[0], 1, -1)))
+            gw = None
+        else:
+            gw = torch.ops.tbe_hip.weighted_colsum(x, gy.view(-1)).view(1, -1)
         gb = gy.sum(dim=0) if ctx.has_bias else None
         return gx, gw, gb
 
