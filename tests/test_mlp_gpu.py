@@ -206,7 +206,8 @@ def test_row_block_partials_sum_to_the_one_pass_results(B, N):
     gx, gb = torch.ops.tbe_hip.relu_backward_bias_grad(gy, act)
     gx2, part = torch.ops.tbe_hip.relu_backward_bias_partials(gy, act)
     assert torch.equal(gx, gx2) and part.shape[1] == N
-    torch.testing.assert_close(part.double().sum(0).float(), gb, rtol=1e-5, atol=1e-4)
+    # the same row-block sums, added in float64 here and in fp32 (another order) by the second-stage kernel
+    torch.testing.assert_close(part.double().sum(0).float(), gb, rtol=1e-4, atol=1e-3)
     w = torch.randn(B, device="cuda")
     torch.testing.assert_close(torch.ops.tbe_hip.weighted_colsum_partials(gy, w).double().sum(0).float(),
-                               torch.ops.tbe_hip.weighted_colsum(gy, w), rtol=1e-5, atol=1e-4)
+                               torch.ops.tbe_hip.weighted_colsum(gy, w), rtol=1e-4, atol=1e-3)
