@@ -139,6 +139,11 @@ def _bce_with_logits(logits, labels):
     key = (dev, stream_ptr(dev))  # one workspace per stream: two streams must not share block partials / the ticket
     ws = _bce_ws.get(key)
     if ws is None:  # [block partials | ticket]: zeroed once, the kernel resets its ticket
+        if torch.cuda.is_current_stream_capturing():
+            # a persistent buffer must not come from a graph's memory pool (an earlier graph of the pool may use its
+            # address for transient tensors and clobber it at every replay): run the op once on this stream before capturing
+            raise RuntimeError("bce_with_logits: first use on this stream happens inside a graph capture; warm the op up "
+                               "on the capture stream first (GraphedSegment does)")
         ws = _bce_ws[key] = torch.zeros(lib.tbe_bce_with_logits_workspace_bytes(), dtype=torch.uint8, device=dev)
     loss = torch.empty((), dtype=torch.float32, device=dev)
     dlogits = torch.empty_like(logits)

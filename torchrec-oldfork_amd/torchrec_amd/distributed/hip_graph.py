@@ -169,9 +169,12 @@ class GraphedSegment(nn.Module):
                     else:
                         rows.append([flat_slice.data_ptr(), 0, n, off])
                     off += n
-                # the segment table lives in the graph's pool (a static address the captured launch reads); its contents —
-                # addresses that are final only now — are uploaded ONCE, right after the capture has ended (below)
-                table = torch.empty((len(rows), 4), dtype=torch.int64, device=sinks[0].device)
+                # the segment table was allocated BEFORE the capture, outside the graphs' memory pool: anything persistent
+                # inside the pool can sit on addresses an EARLIER graph of the pool uses for its transient tensors and would be
+                # overwritten by that graph's every replay (a table placed in the pool produced exactly that: a wild source
+                # pointer and a memory aperture violation in the first replayed step).  Its contents — addresses that are
+                # final only now — are uploaded ONCE, right after the capture has ended (below).
+                table = sink_table
                 torch.ops.tbe_hip.multi_chunk_sum(table, len(rows), max(r[2] for r in rows), flat_slice, float(sink_scale))
                 self._sink_tables.append((table, rows, keep))
             else:
@@ -186,7 +189,9 @@ class GraphedSegment(nn.Module):
 
         self.bwd_graph = torch.cuda.CUDAGraph()
         self.bwd_graph2: Optional[torch.cuda.CUDAGraph] = None
-        self._sink_tables = []  # (device table inside the graph pool, its rows, the source tensors kept alive)
+        self._sink_tables = []  # (device segment table, its rows, the source tensors kept alive)
+        sink_table = (torch.zeros((len(param_grad_sinks), 4), dtype=torch.int64, device=param_grad_sinks[0].device)
+                      if param_grad_sinks else None)  # ordinary allocation: NOT in the graphs' pool (see write_sinks)
         self._stream.synchronize()
         stash = []
         with_partials = bool(defer_wgrad and param_grad_sinks is not None)
