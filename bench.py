@@ -187,6 +187,14 @@ def measure_copy_GBs(torch, dev) -> float:
 def main(args):
     if PKG not in sys.path:
         sys.path.insert(0, PKG)
+    n_ranks = int(os.environ.get("WORLD_SIZE", "1"))
+    if n_ranks > 1 or os.environ.get("TORCHREC_AMD_FORCE_EXCHANGE") == "1":
+        # HIP maps its streams onto this many hardware queues (default 4).  A rank of an N > 1 run uses 7 streams (compute,
+        # memcpy, input dist, the collective's, two sort side streams, graph capture); measured on the one-rank rehearsal
+        # at the 8-GPU per-rank batch: 1 queue 1.867 ms, 2: 1.754, 3: 1.740, 4 (default): 1.785, 8: 3.77 (!) per step
+        # (profiles/r03_rehearsal_b8192_hw_queues.txt); no effect at N = 1 (8.55 vs 8.59 ms).  Read by the runtime when HIP
+        # initialises, so it is set before torch touches the GPU; an explicit value in the environment wins.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")
     import torch
     import torch.distributed as dist
 
@@ -536,6 +544,8 @@ def main(args):
             "rehearsal": (f"{world} ranks on {torch.cuda.device_count()} GPU(s) over gloo, all-to-all staged through the host: "
                           "NOT a multi-GPU timing" if world > 1 and backend == "gloo" else None),
             "launcher": os.environ.get("TORCHREC_AMD_BENCH_LAUNCHER", "external torchrun" if world > 1 else "direct"),
+            "env": {k: os.environ[k] for k in ("GPU_MAX_HW_QUEUES", "HSA_ENABLE_IPC_MODE_LEGACY", "TORCHREC_AMD_RW_INPUT_DIST",
+                                               "TORCHREC_AMD_PREFETCH_LOOKUP", "TORCHREC_AMD_FUSED_BCE") if k in os.environ},
             "config": {"workload": "DLRM Criteo-1TB shape: 26 tables (177.9M rows, 84.85 GiB fp32, D=128), 13 dense, "
                                    "pooling factor 1, dense 512-256-128, over 1024-1024-512-256-1, fused exact SGD",
                        "global_batch": args.global_batch, "local_batch": B_local,

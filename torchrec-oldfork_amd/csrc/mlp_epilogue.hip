@@ -136,10 +136,43 @@ struct ChunkSeg {
 };
 __global__ __launch_bounds__(256) void multi_chunk_sum_kernel(const ChunkSeg* __restrict__ segs, float* __restrict__ dst,
                                                               float scale) {
-  // block = 64 float4 columns x 4 waves; wave w adds chunks w, w + 4, w + 8, ... (8 loads in flight), the four wave sums
-  // are combined through LDS in wave order: the summation order is a function of (chunks) only
+  // many chunks (row-block sums of a bias: 32 ... 1024): block = 64 float4 columns x 4 waves; wave w adds chunks w, w + 4,
+  // w + 8, ... (8 loads in flight), the four wave sums are combined through LDS in wave order.  Few chunks (split-K
+  // slices of a weight: <= 16): block = 256 float4 columns, every thread adds all chunks of its column (all loads in
+  // flight).  Either way the summation order is a function of (chunks) only.
   __shared__ float4 red[4][64];
   const ChunkSeg sg = segs[blockIdx.y];
+  if (sg.chunks <= 16) {  // segment-uniform, hence block-uniform
+    const int64_t j0 = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) * 4;
+    if (j0 >= sg.numel) return;
+    float* o = dst + sg.dst_off + j0;
+    const bool v16 = ((sg.numel & 3) == 0) && ((reinterpret_cast<uintptr_t>(sg.src) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(dst + sg.dst_off) & 15) == 0);
+    if (v16) {
+      float4 a[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+        a[c] = c < sg.chunks ? ld4(sg.src + c * sg.numel + j0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 acc = a[0];
+#pragma unroll
+      for (int c = 1; c < 16; ++c) {
+        if (c < sg.chunks) {
+          acc.x += a[c].x;
+          acc.y += a[c].y;
+          acc.z += a[c].z;
+          acc.w += a[c].w;
+        }
+      }
+      st4(o, make_float4(acc.x * scale, acc.y * scale, acc.z * scale, acc.w * scale));
+    } else {
+      for (int k = 0; k < 4 && j0 + k < sg.numel; ++k) {
+        float acc = 0.f;
+        for (int64_t c = 0; c < sg.chunks; ++c) acc += sg.src[c * sg.numel + j0 + k];
+        o[k] = acc * scale;
+      }
+    }
+    return;
+  }
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int64_t i0 = (static_cast<int64_t>(blockIdx.x) * 64 + lane) * 4;
