@@ -255,7 +255,9 @@ class _Head(nn.Module):
 
     def forward(self, embedded_dense: torch.Tensor, embedded_sparse: torch.Tensor, labels: torch.Tensor):
         logits = self.over_arch(self.inter_arch(dense_features=embedded_dense, sparse_features=embedded_sparse)).squeeze(-1)
-        return bce_with_logits_mean(self.loss_fn, logits, labels), logits
+        # the logits leave the segment for metrics only: detached, so that the captured backward has ONE root (no zero
+        # gradient buffer for a second output, no add of the two contributions to d logits)
+        return bce_with_logits_mean(self.loss_fn, logits, labels), logits.detach()
 
 
 class DLRMTrain(nn.Module):
