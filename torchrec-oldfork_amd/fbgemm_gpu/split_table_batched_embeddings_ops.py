@@ -371,6 +371,11 @@ class _TBEBase(nn.Module):
         # side-stream sort steals bandwidth from the GEMMs, -2 %; at 213 K ids it hides, +4 %)
         self.overlap_backward_sort = os.environ.get("TBE_OVERLAP_SORT", "auto")
         self.overlap_backward_sort_max_ids = 1 << 22  # the one-launch-per-pass sort no longer steals GEMM bandwidth
+        # ... in EAGER steps.  In the explicit (HIP-graph) step the dense segments replay back to back and a concurrent sort
+        # costs more than it hides once it is big: one-rank rehearsal, overlap on / off, ms per step at per-rank batch
+        # 4096: 0.936 / 0.954, 8192: 1.736 / 1.740, 16384: 2.943 / 2.880, 32768: 5.72 / 5.26 (ids per lookup 53 K ... 491 K;
+        # eager at 65 536: 8.455 / 8.544).  lookup_no_autograd() therefore overlaps only below this many ids.
+        self.overlap_backward_sort_max_ids_explicit = int(os.environ.get("TBE_OVERLAP_SORT_EXPLICIT_MAX_IDS", "200000"))
 
     def __getstate__(self):
         # copy.deepcopy / pickling (model_parallel.py:294-298 deep-copies sharded modules): HIP streams
@@ -1044,7 +1049,7 @@ class SplitTableBatchedEmbeddingBagsCodegen(_TBEBase):
         rec = LookupRecord(indices, offsets, per_sample_weights, B, (into[1], int(into[2])) if into is not None else None)
         out = self._forward_impl(indices, offsets, per_sample_weights, B, into=into)
         mode = self.overlap_backward_sort
-        if mode in (True, "1") or (mode == "auto" and indices.numel() <= self.overlap_backward_sort_max_ids):
+        if mode in (True, "1") or (mode == "auto" and indices.numel() <= self.overlap_backward_sort_max_ids_explicit):
             rec.prepared = self._prepare_or_defer(rec, indices, offsets, B, per_sample_weights is not None)
         self._enforce_bounds_check_mode()
         return out, rec
@@ -1147,7 +1152,7 @@ class DenseTableBatchedEmbeddingBagsCodegen(_TBEBase):
         # the gradient-independent half of the backward (linearize + sort: 5 dependent launches, ~25 us of latency for the
         # ~90 K ids of the replicated tiny tables) starts now on the module's side stream, as the fused module's does
         mode = self.overlap_backward_sort
-        if mode in (True, "1") or (mode == "auto" and indices.numel() <= self.overlap_backward_sort_max_ids):
+        if mode in (True, "1") or (mode == "auto" and indices.numel() <= self.overlap_backward_sort_max_ids_explicit):
             rec.prepared = self._prepare_backward(indices, offsets, B, per_sample_weights is not None)
         return out, rec
 
