@@ -375,7 +375,7 @@ class _TBEBase(nn.Module):
         # costs more than it hides once it is big: one-rank rehearsal, overlap on / off, ms per step at per-rank batch
         # 4096: 0.936 / 0.954, 8192: 1.736 / 1.740, 16384: 2.943 / 2.880, 32768: 5.72 / 5.26 (ids per lookup 53 K ... 491 K;
         # eager at 65 536: 8.455 / 8.544).  lookup_no_autograd() therefore overlaps only below this many ids.
-        self.overlap_backward_sort_max_ids_explicit = int(os.environ.get("TBE_OVERLAP_SORT_EXPLICIT_MAX_IDS", "200000"))
+        self.overlap_backward_sort_max_ids_explicit = int(os.environ.get("TBE_OVERLAP_SORT_EXPLICIT_MAX_IDS", "150000"))
 
     def __getstate__(self):
         # copy.deepcopy / pickling (model_parallel.py:294-298 deep-copies sharded modules): HIP streams
