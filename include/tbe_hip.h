@@ -437,6 +437,11 @@ int tbe_weighted_colsum_partials_f32(const float* x, const float* w, int64_t B, 
  * (torchrec/distributed/model_parallel.py:101-111). */
 int tbe_multi_chunk_sum_f32(const int64_t* seg_table, int32_t nseg, int64_t max_numel, float* dst, float scale,
                             void* stream);
+/* The same with the table in HOST memory, at most 32 segments: it travels by value in the kernel arguments (no copy the
+ * GPU performs later, so the caller may reuse the host buffer at once) — for eager steps, whose sources and destinations
+ * change every step.  With dst = NULL the destination offsets are absolute addresses / 4. */
+int tbe_multi_chunk_sum_host_table_f32(const int64_t* host_seg_table, int32_t nseg, int64_t max_numel, float* dst,
+                                       float scale, void* stream);
 
 /* nn.BCEWithLogitsLoss (mean) forward + gradient in one launch — the loss of the reference's train wrapper
  * (examples/dlrm/modules/dlrm_train.py):  loss = mean_i [max(x_i, 0) - x_i y_i + log1p(exp(-|x_i|))],

@@ -211,3 +211,32 @@ def test_row_block_partials_sum_to_the_one_pass_results(B, N):
     w = torch.randn(B, device="cuda")
     torch.testing.assert_close(torch.ops.tbe_hip.weighted_colsum_partials(gy, w).double().sum(0).float(),
                                torch.ops.tbe_hip.weighted_colsum(gy, w), rtol=1e-4, atol=1e-3)
+
+
+def test_deferred_finish_of_an_eager_backward_equals_the_plain_path():
+    """modules/mlp.py _DeferredFinish: with the switch on, an eager backward hands out unfinished weight / bias gradients
+    and ONE launch (segment table by value in the kernel arguments) finishes them all; same values as the plain path to
+    fp32 summation order, nothing pending afterwards, off again after disable()."""
+    from torchrec_amd.modules.mlp import MLP, LinearOut, _DeferredFinish
+
+    def run(deferred):
+        torch.manual_seed(3)
+        mlp = MLP(479, [1024, 512, 256], device=torch.device("cuda"))
+        last = LinearOut(256, 1, device=torch.device("cuda"))
+        x = torch.randn(16384, 479, device="cuda")
+        y = last(mlp(x))
+        if deferred:
+            _DeferredFinish.enable()
+        try:
+            y.sum().backward()
+            if deferred:
+                assert len(_DeferredFinish.pending) >= 6  # 3 split-K weights, 3 biases, the one-output weight
+        finally:
+            if deferred:
+                _DeferredFinish.disable()
+        assert not _DeferredFinish.pending and not _DeferredFinish.on
+        return [p.grad.clone() for p in list(mlp.parameters()) + list(last.parameters())]
+
+    a, b = run(False), run(True)
+    for g0, g1 in zip(a, b):
+        torch.testing.assert_close(g1, g0, rtol=2e-4, atol=2e-3)

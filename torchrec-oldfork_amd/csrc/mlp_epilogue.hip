@@ -8,6 +8,7 @@
 // HBM-bound elementwise work between the library GEMMs of the dense MLPs — the only place, besides
 // the dot interaction, where this build touches the dense side.
 #include <algorithm>
+#include <cstring>
 
 #include "common.hpp"
 
@@ -134,14 +135,29 @@ struct ChunkSeg {
   int64_t numel;
   int64_t dst_off;
 };
+constexpr int kChunkSegsByValue = 32;
+struct ChunkSegs32 {
+  ChunkSeg s[kChunkSegsByValue];
+};
+__device__ __forceinline__ void multi_chunk_sum_body(const ChunkSeg sg, float* __restrict__ dst, float scale);
+
+// segment table in device memory (captured backward graphs: a static table per segment)
 __global__ __launch_bounds__(256) void multi_chunk_sum_kernel(const ChunkSeg* __restrict__ segs, float* __restrict__ dst,
                                                               float scale) {
+  multi_chunk_sum_body(segs[blockIdx.y], dst, scale);
+}
+// segment table passed BY VALUE in the kernel arguments (eager steps: sources and destinations change every step, and a
+// host buffer the GPU reads later could be overwritten by a host that runs many steps ahead)
+__global__ __launch_bounds__(256) void multi_chunk_sum_args_kernel(const ChunkSegs32 segs, float* __restrict__ dst, float scale) {
+  multi_chunk_sum_body(segs.s[blockIdx.y], dst, scale);
+}
+
+__device__ __forceinline__ void multi_chunk_sum_body(const ChunkSeg sg, float* __restrict__ dst, float scale) {
   // many chunks (row-block sums of a bias: 32 ... 1024): block = 64 float4 columns x 4 waves; wave w adds chunks w, w + 4,
   // w + 8, ... (8 loads in flight), the four wave sums are combined through LDS in wave order.  Few chunks (split-K
   // slices of a weight: <= 16): block = 256 float4 columns, every thread adds all chunks of its column (all loads in
   // flight).  Either way the summation order is a function of (chunks) only.
   __shared__ float4 red[4][64];
-  const ChunkSeg sg = segs[blockIdx.y];
   if (sg.chunks <= 16) {  // segment-uniform, hence block-uniform
     const int64_t j0 = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) * 4;
     if (j0 >= sg.numel) return;
@@ -432,6 +448,22 @@ extern "C" int tbe_multi_chunk_sum_f32(const int64_t* seg_table, int32_t nseg, i
   hipLaunchKernelGGL(multi_chunk_sum_kernel, dim3(static_cast<unsigned>(tiles), static_cast<unsigned>(nseg)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), reinterpret_cast<const ChunkSeg*>(seg_table), dst, scale);
   TBE_CHECK_LAUNCH("tbe_multi_chunk_sum_f32");
+  return TBE_OK;
+}
+
+extern "C" int tbe_multi_chunk_sum_host_table_f32(const int64_t* host_seg_table, int32_t nseg, int64_t max_numel, float* dst,
+                                                  float scale, void* stream) {
+  TBE_REQUIRE(nseg >= 0 && nseg <= kChunkSegsByValue && max_numel >= 0,
+              "tbe_multi_chunk_sum_host_table_f32: 0 <= nseg <= %d required", kChunkSegsByValue);
+  if (nseg == 0 || max_numel == 0) return TBE_OK;
+  TBE_REQUIRE(host_seg_table != nullptr, "tbe_multi_chunk_sum_host_table_f32: null table");
+  ChunkSegs32 segs{};
+  memcpy(segs.s, host_seg_table, static_cast<size_t>(nseg) * sizeof(ChunkSeg));
+  const int64_t tiles = (max_numel + 255) / 256;
+  TBE_REQUIRE(tiles < (1ll << 31), "tbe_multi_chunk_sum_host_table_f32: segment too long");
+  hipLaunchKernelGGL(multi_chunk_sum_args_kernel, dim3(static_cast<unsigned>(tiles), static_cast<unsigned>(nseg)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), segs, dst, scale);
+  TBE_CHECK_LAUNCH("tbe_multi_chunk_sum_host_table_f32");
   return TBE_OK;
 }
 

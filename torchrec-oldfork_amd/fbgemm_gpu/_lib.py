@@ -147,6 +147,7 @@ SIGNATURES = {
     "tbe_weighted_colsum_partials_f32": (
         ctypes.c_int, [c_void_p, c_void_p, c_i64, c_i32, c_void_p, c_size, c_void_p]),
     "tbe_multi_chunk_sum_f32": (ctypes.c_int, [c_void_p, c_i32, c_i64, c_void_p, c_float, c_void_p]),
+    "tbe_multi_chunk_sum_host_table_f32": (ctypes.c_int, [c_void_p, c_i32, c_i64, c_void_p, c_float, c_void_p]),
     "tbe_bce_with_logits_workspace_bytes": (c_size, []),
     "tbe_bce_with_logits_f32": (
         ctypes.c_int, [c_void_p, c_void_p, c_i32, c_i64, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),

@@ -102,6 +102,9 @@ class TrainPipelineSparseDist:
         if want is None:
             want = os.environ.get("TORCHREC_AMD_WGRAD_OVERLAP", "0") == "1"
         self._wgrad_overlap = bool(want and ok)
+        # eager steps: the dense gradients' final reductions in one launch (modules/mlp.py _DeferredFinish): the same
+        # preconditions (this pipeline calls finish_dense_grads() right after backward, no DistributedDataParallel hooks)
+        self._deferred_finish = bool(ok and os.environ.get("TORCHREC_AMD_DEFERRED_FINISH", "1") != "0")
 
     def _install(self) -> None:
         root = self._model.module if isinstance(self._model, DistributedModelParallel) else self._model
@@ -134,6 +137,24 @@ class TrainPipelineSparseDist:
         with label("## prefetch_next_lookup ##"):
             step = w.compute_explicit(nxt.sparse_features)
         return (nxt.sparse_features, step) if step is not None else None
+
+    def _dense_params(self):
+        ps = getattr(self, "_dense_param_list", None)
+        if ps is None:
+            ps = self._dense_param_list = [p for p in self._model.parameters() if p.requires_grad]
+        return ps
+
+    def _run_backward(self, losses) -> None:
+        if self._wgrad_overlap:
+            from ..modules.mlp import _WgradOverlap
+
+            _WgradOverlap.enable(self._device)  # for this backward only: joined right below
+            try:
+                torch.sum(losses, dim=0).backward()
+            finally:
+                _WgradOverlap.disable()
+        else:
+            torch.sum(losses, dim=0).backward()
 
     def _to_device(self, batch, non_blocking: bool):
         return batch.to(self._device, non_blocking=non_blocking) if batch is not None else None
@@ -240,16 +261,17 @@ class TrainPipelineSparseDist:
                 self._optimizer.step()
         elif self._model.training:
             with label("## backward ##"):  # train_pipeline.py:546
-                if self._wgrad_overlap:
-                    from ..modules.mlp import _WgradOverlap
+                from ..modules.mlp import _DeferredFinish
 
-                    _WgradOverlap.enable(self._device)  # for this backward only: joined right below
-                    try:
-                        torch.sum(losses, dim=0).backward()
-                    finally:
-                        _WgradOverlap.disable()
-                else:
-                    torch.sum(losses, dim=0).backward()
+                # unfinished gradient tensors must never meet an accumulating AccumulateGrad: every dense .grad is None
+                deferred = self._deferred_finish and all(p.grad is None for p in self._dense_params())
+                if deferred:
+                    _DeferredFinish.enable()
+                try:
+                    self._run_backward(losses)
+                finally:
+                    if deferred:
+                        _DeferredFinish.disable()  # flushes
             with label("## optimizer ##"):
                 if hasattr(root, "finish_dense_grads"):
                     root.finish_dense_grads()  # flat-buffer gradient all-reduce of graphed segments (models/dlrm.py)

@@ -423,9 +423,10 @@ class DLRMTrain(nn.Module):
         """After backward: folds the autograd gradients of the non-graphed dense parameters into the flat
         buffer, all-reduces the rest of it (bottom segment + those), waits, and attaches the slices as
         `.grad` (every rank then holds the rank-averaged gradient, as under DistributedDataParallel)."""
-        from ..modules.mlp import _WgradOverlap
+        from ..modules.mlp import _DeferredFinish, _WgradOverlap
 
         _WgradOverlap.join()  # weight gradients computed on the side stream (eager steps; modules/mlp.py)
+        _DeferredFinish.flush()  # eager steps: every split-K / bias gradient of this backward finished by one launch
         st = getattr(self, "_flat_dense", None)
         if st is None:
             return
