@@ -214,9 +214,10 @@ def test_row_block_partials_sum_to_the_one_pass_results(B, N):
 
 
 def test_deferred_finish_of_an_eager_backward_equals_the_plain_path():
-    """modules/mlp.py _DeferredFinish: with the switch on, an eager backward hands out unfinished weight / bias gradients
-    and ONE launch (segment table by value in the kernel arguments) finishes them all; same values as the plain path to
-    fp32 summation order, nothing pending afterwards, off again after disable()."""
+    """modules/mlp.py _DeferredFinish: with the switch on, an eager backward leaves the split-K weight gradients and the
+    bias gradients to ONE launch (segment table by value in the kernel arguments) that also attaches them as .grad
+    (accumulating into an existing one); same values as the plain path to fp32 summation order, nothing pending afterwards,
+    off again after disable()."""
     from torchrec_amd.modules.mlp import MLP, LinearOut, _DeferredFinish
 
     def run(deferred):
@@ -240,3 +241,12 @@ def test_deferred_finish_of_an_eager_backward_equals_the_plain_path():
     a, b = run(False), run(True)
     for g0, g1 in zip(a, b):
         torch.testing.assert_close(g1, g0, rtol=2e-4, atol=2e-3)
+    # accumulation into an existing .grad
+    lin = LinearOut(256, 1, device=torch.device("cuda"))
+    x = torch.randn(4096, 256, device="cuda")
+    lin(x).sum().backward()
+    once = lin.weight.grad.clone()
+    _DeferredFinish.enable()
+    lin(x).sum().backward()
+    _DeferredFinish.disable()
+    torch.testing.assert_close(lin.weight.grad, 2 * once, rtol=2e-4, atol=2e-3)

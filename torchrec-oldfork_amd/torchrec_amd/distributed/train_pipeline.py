@@ -138,12 +138,6 @@ class TrainPipelineSparseDist:
             step = w.compute_explicit(nxt.sparse_features)
         return (nxt.sparse_features, step) if step is not None else None
 
-    def _dense_params(self):
-        ps = getattr(self, "_dense_param_list", None)
-        if ps is None:
-            ps = self._dense_param_list = [p for p in self._model.parameters() if p.requires_grad]
-        return ps
-
     def _run_backward(self, losses) -> None:
         if self._wgrad_overlap:
             from ..modules.mlp import _WgradOverlap
@@ -263,8 +257,7 @@ class TrainPipelineSparseDist:
             with label("## backward ##"):  # train_pipeline.py:546
                 from ..modules.mlp import _DeferredFinish
 
-                # unfinished gradient tensors must never meet an accumulating AccumulateGrad: every dense .grad is None
-                deferred = self._deferred_finish and all(p.grad is None for p in self._dense_params())
+                deferred = self._deferred_finish
                 if deferred:
                     _DeferredFinish.enable()
                 try:

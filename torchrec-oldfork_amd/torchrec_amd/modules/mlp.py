@@ -92,16 +92,17 @@ class _DeferredFinish:
 
     The split-K weight gradient of a layer ends in a reduce kernel over its batch slices, the bias gradient in a second-stage
     column-sum launch: 16 launches per DLRM step whose combined work is ~50 MB (≈ 140 us per step at batch 65 536).  With this
-    switch on, `backward` hands autograd UNFINISHED gradient tensors and records (partial sums [chunks, numel], destination);
+    switch on, `backward` returns NO gradient for those parameters and records (parameter, partial sums [chunks, numel]);
     `flush()` adds every parameter's chunks in fixed order with one `multi_chunk_sum` launch (segment table by value in the
-    kernel arguments).  Only for an owner that (a) calls flush() after backward and before anything reads the gradients —
-    TrainPipelineSparseDist does, through DLRMTrain.finish_dense_grads — and (b) starts backward with `.grad is None` for
-    the dense parameters (an AccumulateGrad that ADDS would read the unfinished tensor): the pipeline checks both and
-    enables it for the duration of one backward, never under DistributedDataParallel (its hooks read gradients as they
-    arrive) and never inside a HIP-graph capture (captures have their own stash: _DeferredWgrad)."""
+    kernel arguments) and attaches the results as `.grad` itself (accumulating into an existing `.grad`), the way
+    `_WgradOverlap` does — handing autograd an unfinished tensor does not work: AccumulateGrad clones a gradient somebody
+    else still references.  Only for an owner that calls flush() after backward and before anything reads the gradients —
+    TrainPipelineSparseDist does, through DLRMTrain.finish_dense_grads — and enables it for the duration of one backward;
+    never under DistributedDataParallel (its hooks wait for gradients autograd never delivers) and never inside a HIP-graph
+    capture (captures have their own stash: _DeferredWgrad)."""
 
     on: bool = False
-    pending: list = []  # (partials [chunks, numel] fp32 contiguous, destination tensor)
+    pending: list = []  # (parameter, partials [chunks, numel] fp32 contiguous)
     MAX_SEGMENTS = 32
 
     @classmethod
@@ -114,12 +115,13 @@ class _DeferredFinish:
         cls.on = False
 
     @classmethod
-    def active_for(cls, t: torch.Tensor) -> bool:
-        return cls.on and t.is_cuda and t.dtype == torch.float32 and not torch.cuda.is_current_stream_capturing()
+    def active_for(cls, t: torch.Tensor, param) -> bool:
+        return (cls.on and param is not None and t.is_cuda and t.dtype == torch.float32 and param.dtype == torch.float32
+                and not torch.cuda.is_current_stream_capturing())
 
     @classmethod
-    def add(cls, partials: torch.Tensor, dst: torch.Tensor) -> None:
-        cls.pending.append((partials.contiguous().view(partials.shape[0], -1), dst))
+    def add(cls, param, partials: torch.Tensor) -> None:
+        cls.pending.append((param, partials.contiguous().view(partials.shape[0], -1)))
         if len(cls.pending) >= cls.MAX_SEGMENTS:
             cls.flush()
 
@@ -135,13 +137,22 @@ class _DeferredFinish:
         items, cls.pending = cls.pending, []
         dev = items[0][1].device
         table = (ctypes.c_int64 * (4 * len(items)))()
-        for i, (part, dst) in enumerate(items):
-            if part.shape[1] != dst.numel() or not dst.is_contiguous() or dst.device != dev or part.device != dev:
-                raise RuntimeError("_DeferredFinish: partial sums do not match their destination")
+        outs = []
+        for i, (prm, part) in enumerate(items):
+            if part.shape[1] != prm.numel() or part.device != dev:
+                raise RuntimeError("_DeferredFinish: partial sums do not match their parameter")
+            dst = torch.empty(prm.shape, dtype=torch.float32, device=dev)
+            outs.append(dst)
             table[4 * i:4 * i + 4] = [part.data_ptr(), part.shape[0], dst.numel(), dst.data_ptr() // 4]
         with torch.cuda.device(dev):
-            check(_lib.load().tbe_multi_chunk_sum_host_table_f32(table, len(items), max(d.numel() for _, d in items), None, 1.0,
+            check(_lib.load().tbe_multi_chunk_sum_host_table_f32(table, len(items), max(d.numel() for d in outs), None, 1.0,
                                                                  stream_ptr(dev)), "tbe_multi_chunk_sum_host_table_f32")
+        with torch.no_grad():
+            for (prm, _), dst in zip(items, outs):
+                if prm.grad is None:
+                    prm.grad = dst
+                else:
+                    prm.grad.add_(dst)
 
 
 class _LinearSplitKWgrad(torch.autograd.Function):
@@ -183,10 +194,10 @@ class _LinearSplitKWgrad(torch.autograd.Function):
                     gy, part = torch.ops.tbe_hip.relu_backward_bias_partials(gy, out)
                     _DeferredWgrad.pending.append(("p", ctx.bias_param, part))
                     gb_deferred = True
-                elif ctx.needs_input_grad[2] and _DeferredFinish.active_for(gy):
+                elif ctx.needs_input_grad[2] and _DeferredFinish.active_for(gy, ctx.bias_param):
                     gy, part = torch.ops.tbe_hip.relu_backward_bias_partials(gy, out)
-                    gb = torch.empty(out.shape[1], dtype=torch.float32, device=gy.device)  # finished by _DeferredFinish.flush()
-                    _DeferredFinish.add(part, gb)
+                    _DeferredFinish.add(ctx.bias_param, part)  # .grad attached by _DeferredFinish.flush()
+                    gb_deferred = True
                 else:
                     gy, gb = torch.ops.tbe_hip.relu_backward_bias_grad(gy, out)
             else:
@@ -231,10 +242,10 @@ class _LinearSplitKWgrad(torch.autograd.Function):
             gw.record_stream(cur)      # read by the optimizer on the main stream after join()
             _WgradOverlap.pending.append(done)
             gw = None
-        elif ctx.needs_input_grad[1] and c > 1 and B % c == 0 and _DeferredFinish.active_for(gy):
-            part = _DeferredWgrad.compute_partials(gy, x, c)  # [c, out, in]: the batched GEMM without its reduction
-            gw = torch.empty(part.shape[1:], dtype=torch.float32, device=gy.device)  # finished by _DeferredFinish.flush()
-            _DeferredFinish.add(part, gw)
+        elif ctx.needs_input_grad[1] and c > 1 and B % c == 0 and _DeferredFinish.active_for(gy, w):
+            # [c, out, in]: the batched GEMM without its reduction; .grad attached by _DeferredFinish.flush()
+            _DeferredFinish.add(w, _DeferredWgrad.compute_partials(gy, x, c))
+            gw = None
         else:
             gw = wgrad()
         if gb is None and ctx.has_bias and not gb_deferred:
@@ -265,10 +276,9 @@ class _LinearOneOutput(torch.autograd.Function):
             part = torch.ops.tbe_hip.weighted_colsum_partials(x, gy.view(-1))  # [row blocks, in]
             _DeferredWgrad.pending.append(("p", ctx.weight_param, part.view(part.shape[0], 1, -1)))
             gw = None
-        elif ctx.needs_input_grad[1] and _DeferredFinish.active_for(gy):
-            part = torch.ops.tbe_hip.weighted_colsum_partials(x, gy.view(-1))
-            gw = torch.empty((1, x.shape[1]), dtype=torch.float32, device=gy.device)  # finished by _DeferredFinish.flush()
-            _DeferredFinish.add(part, gw)
+        elif ctx.needs_input_grad[1] and _DeferredFinish.active_for(gy, ctx.weight_param):
+            _DeferredFinish.add(ctx.weight_param, torch.ops.tbe_hip.weighted_colsum_partials(x, gy.view(-1)))
+            gw = None
         else:
             gw = torch.ops.tbe_hip.weighted_colsum(x, gy.view(-1)).view(1, -1)
         gb = gy.sum(dim=0) if ctx.has_bias else None
