@@ -103,8 +103,11 @@ class TrainPipelineSparseDist:
             want = os.environ.get("TORCHREC_AMD_WGRAD_OVERLAP", "0") == "1"
         self._wgrad_overlap = bool(want and ok)
         # eager steps: the dense gradients' final reductions in one launch (modules/mlp.py _DeferredFinish): the same
-        # preconditions (this pipeline calls finish_dense_grads() right after backward, no DistributedDataParallel hooks)
-        self._deferred_finish = bool(ok and os.environ.get("TORCHREC_AMD_DEFERRED_FINISH", "1") != "0")
+        # preconditions (this pipeline calls finish_dense_grads() right after backward, no DistributedDataParallel hooks).
+        # Opt-in (TORCHREC_AMD_DEFERRED_FINISH=1): measured neutral at batch 65 536 (8.549 / 8.573 ms with, 8.504 / 8.560
+        # without, same box) — an eager step of that size is bound by bytes, not by its 16 small launches; the graph-mode
+        # counterpart (hip_graph.py write_sinks) is what pays, at the per-rank batches of N > 1.
+        self._deferred_finish = bool(ok and os.environ.get("TORCHREC_AMD_DEFERRED_FINISH", "0") == "1")
 
     def _install(self) -> None:
         root = self._model.module if isinstance(self._model, DistributedModelParallel) else self._model
