@@ -236,6 +236,11 @@ def main(args):
         with native_stdout_to_stderr():
             if rehearse:
                 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+                link_us = float(os.environ.get("TORCHREC_AMD_REHEARSAL_LINK_US", "0"))
+                if link_us > 0:  # the pooled all-to-alls take this long on the GPU timeline, as over xGMI
+                    from torchrec_amd.distributed._rehearsal import emulate_link_time
+
+                    emulate_link_time(link_us)
             elif backend == "gloo":
                 from torchrec_amd.distributed._rehearsal import stage_all_to_all_through_host
 
@@ -545,7 +550,8 @@ def main(args):
                           "NOT a multi-GPU timing" if world > 1 and backend == "gloo" else None),
             "launcher": os.environ.get("TORCHREC_AMD_BENCH_LAUNCHER", "external torchrun" if world > 1 else "direct"),
             "env": {k: os.environ[k] for k in ("GPU_MAX_HW_QUEUES", "HSA_ENABLE_IPC_MODE_LEGACY", "TORCHREC_AMD_RW_INPUT_DIST",
-                                               "TORCHREC_AMD_PREFETCH_LOOKUP", "TORCHREC_AMD_FUSED_BCE") if k in os.environ},
+                                               "TORCHREC_AMD_PREFETCH_LOOKUP", "TORCHREC_AMD_FUSED_BCE",
+                                               "TORCHREC_AMD_REHEARSAL_LINK_US") if k in os.environ},
             "config": {"workload": "DLRM Criteo-1TB shape: 26 tables (177.9M rows, 84.85 GiB fp32, D=128), 13 dense, "
                                    "pooling factor 1, dense 512-256-128, over 1024-1024-512-256-1, fused exact SGD",
                        "global_batch": args.global_batch, "local_batch": B_local,
