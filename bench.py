@@ -233,9 +233,11 @@ def main(args):
     if world > 1 or rehearse:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
+        from torchrec_amd.distributed.comm import init_rccl_process_group
+
         with native_stdout_to_stderr():
             if rehearse:
-                dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+                init_rccl_process_group(dev, rank=0, world_size=1)
                 link_us = float(os.environ.get("TORCHREC_AMD_REHEARSAL_LINK_US", "0"))
                 if link_us > 0:  # the pooled all-to-alls take this long on the GPU timeline, as over xGMI
                     from torchrec_amd.distributed._rehearsal import emulate_link_time
@@ -247,7 +249,7 @@ def main(args):
                 dist.init_process_group("gloo")
                 stage_all_to_all_through_host()
             else:
-                dist.init_process_group("nccl", device_id=dev)
+                init_rccl_process_group(dev)
             dist.barrier()  # the communicator (and its banner) exists before stdout is handed back
         env = ShardingEnv.from_process_group(dist.group.WORLD)
     else:
@@ -551,7 +553,8 @@ def main(args):
             "launcher": os.environ.get("TORCHREC_AMD_BENCH_LAUNCHER", "external torchrun" if world > 1 else "direct"),
             "env": {k: os.environ[k] for k in ("GPU_MAX_HW_QUEUES", "HSA_ENABLE_IPC_MODE_LEGACY", "TORCHREC_AMD_RW_INPUT_DIST",
                                                "TORCHREC_AMD_PREFETCH_LOOKUP", "TORCHREC_AMD_FUSED_BCE",
-                                               "TORCHREC_AMD_REHEARSAL_LINK_US") if k in os.environ},
+                                               "TORCHREC_AMD_REHEARSAL_LINK_US", "TORCHREC_AMD_RCCL_HIGH_PRIORITY",
+                                               "TBE_STREAM_PROBE") if k in os.environ},
             "config": {"workload": "DLRM Criteo-1TB shape: 26 tables (177.9M rows, 84.85 GiB fp32, D=128), 13 dense, "
                                    "pooling factor 1, dense 512-256-128, over 1024-1024-512-256-1, fused exact SGD",
                        "global_batch": args.global_batch, "local_batch": B_local,

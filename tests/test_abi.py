@@ -107,3 +107,17 @@ def test_recorded_gemm_choices_file_is_well_formed():
     assert len({(r[0], r[1]) for r in rows}) == len(rows)
     assert any("_65536_" in r[1] for r in rows) and any("_8192_" in r[1] for r in rows)
     assert os.path.basename(tuning._FILE) == "gemm_gfx950_dlrm.csv"
+
+
+def test_rccl_options_put_the_collective_stream_on_its_own_priority(monkeypatch):
+    """torchrec_amd/distributed/comm.py: high-priority collective stream by default (its own hardware queue)."""
+    import torch.distributed as dist
+
+    if not hasattr(dist, "ProcessGroupNCCL"):
+        pytest.skip("torch built without the nccl (RCCL) backend")
+    from torchrec_amd.distributed.comm import rccl_options
+
+    assert rccl_options().is_high_priority_stream is True
+    assert rccl_options(False).is_high_priority_stream is False
+    monkeypatch.setenv("TORCHREC_AMD_RCCL_HIGH_PRIORITY", "0")
+    assert rccl_options().is_high_priority_stream is False

@@ -19,7 +19,7 @@ from typing import List, Optional, Tuple
 import torch
 from torch import nn
 
-from . import _lib
+from . import _lib, _streams
 from ._lib import CacheDesc, OptimizerArgs, check, ptr, raise_on_faults, require_gpu, stream_ptr, workspace
 from .split_embedding_configs import EmbOptimType as OptimType
 from .split_embedding_configs import SparseType
@@ -665,7 +665,7 @@ class _TBEBase(nn.Module):
             ws = workspace(nbytes, dev)
             side = self._side_stream
             if side is None or side.device != dev:
-                side = self._side_stream = torch.cuda.Stream(dev)
+                side = self._side_stream = _streams.side_stream(dev)
             cur = torch.cuda.current_stream(dev)
             side.wait_stream(cur)
             for t in (ws, indices, offsets):

@@ -9,6 +9,7 @@ HIP graphs, the explicit step, the flat-gradient all-reduce (gloo reduces device
 CUs and HBM and the exchange crosses the host."""
 import torch
 import torch.distributed as dist
+from fbgemm_gpu._streams import side_stream
 
 _real_all_to_all_single = None
 
@@ -61,7 +62,7 @@ def emulate_link_time(fwd_us: float) -> None:
     b.record()
     b.synchronize()
     cycles_per_us = 10_000_000 / (a.elapsed_time(b) * 1e3)
-    _link_state.update(stream=torch.cuda.Stream(dev), cycles=int(fwd_us * cycles_per_us), us=fwd_us)
+    _link_state.update(stream=side_stream(dev), cycles=int(fwd_us * cycles_per_us), us=fwd_us)
     real = dist.all_to_all_single
 
     def all_to_all_single(output, input, output_split_sizes=None, input_split_sizes=None, group=None, async_op=False):

@@ -1,0 +1,29 @@
+"""Process-group set-up for one process per GPU over RCCL.
+
+Why a helper: HIP maps every stream of a process onto a few hardware queues (GPU_MAX_HW_QUEUES of them per priority level),
+and two streams on one hardware queue execute in order.  ProcessGroupNCCL takes its internal stream from torch's pool, so
+by default the collective's stream can land on the hardware queue of the compute stream: a pooled all-to-all that waits for
+its link then holds back every compute kernel enqueued behind it (kernel trace, `Queue_Id` column — the RCCL
+kernels and the default stream's kernels on one queue; both all-to-alls of a step fully exposed).  Hardware queues are kept
+per priority level, so a HIGH-PRIORITY collective stream never shares one with the normal-priority compute streams — and a
+collective should start as soon as its input is there anyway."""
+import os
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+def rccl_options(high_priority: Optional[bool] = None):
+    """ProcessGroupNCCL.Options for `init_process_group(..., pg_options=)` / `new_group(..., pg_options=)`.
+    high_priority None: TORCHREC_AMD_RCCL_HIGH_PRIORITY (default 1)."""
+    if high_priority is None:
+        high_priority = os.environ.get("TORCHREC_AMD_RCCL_HIGH_PRIORITY", "1") == "1"
+    opts = dist.ProcessGroupNCCL.Options()
+    opts.is_high_priority_stream = bool(high_priority)
+    return opts
+
+
+def init_rccl_process_group(device: torch.device, high_priority: Optional[bool] = None, **kwargs) -> None:
+    """`dist.init_process_group("nccl", device_id=device, ...)` with the collective stream on its own hardware queue."""
+    dist.init_process_group("nccl", device_id=device, pg_options=rccl_options(high_priority), **kwargs)

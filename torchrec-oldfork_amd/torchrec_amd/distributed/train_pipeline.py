@@ -11,6 +11,8 @@ from typing import Any, Iterator, List, Optional, Tuple
 
 import torch
 
+from fbgemm_gpu._streams import side_stream
+
 from ..profiling import label
 from .model_parallel import DistributedModelParallel
 
@@ -69,8 +71,9 @@ class TrainPipelineSparseDist:
         if isinstance(model, DistributedModelParallel) and model.is_data_parallel_wrapped():
             self._hip_graphs = False
         use_streams = device.type == "cuda"
-        self._memcpy_stream = torch.cuda.Stream(device) if use_streams else None
-        self._data_dist_stream = torch.cuda.Stream(device) if use_streams else None
+        # streams on other hardware queues than the compute stream's (fbgemm_gpu/_streams.py)
+        self._memcpy_stream = side_stream(device) if use_streams else None
+        self._data_dist_stream = side_stream(device) if use_streams else None
         self._requests = {}
         # explicit-step models: enqueue batch i+1's lookup + pooled all-to-all right behind batch i's embedding backward
         # (prefetch_lookup=True or TORCHREC_AMD_PREFETCH_LOOKUP=1).  Opt-in: in the one-rank rehearsal at the 8-GPU per-rank

@@ -30,7 +30,9 @@ class _WgradOverlap:
             import os
 
             # numerically larger = lower priority; the runtime clamps to what the device offers
-            cls.stream = torch.cuda.Stream(device, priority=int(os.environ.get("TORCHREC_AMD_WGRAD_PRIORITY", "0")))
+            from fbgemm_gpu._streams import side_stream
+
+            cls.stream = side_stream(device, priority=int(os.environ.get("TORCHREC_AMD_WGRAD_PRIORITY", "0")))
         cls.on = True
 
     @classmethod
