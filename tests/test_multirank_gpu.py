@@ -245,7 +245,9 @@ def _rccl_worker(rank, port, fixed_len, weighted, dp_max_rows, ret):
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from torchrec_amd.distributed.comm import init_rccl_process_group
+
+    init_rccl_process_group(torch.device("cuda", 0), rank=0, world_size=1)
     try:
         import torchrec_amd.distributed.embeddingbag as eb
         from torchrec_amd.distributed.types import ShardingEnv

@@ -204,6 +204,7 @@ class _ExchangeState:
         self.work = None
         self.grad_recv: Optional[torch.Tensor] = None
         self.bwd_work = None
+        self._dest: Optional[torch.Tensor] = None
 
     def start_forward(self, emb: torch.Tensor) -> None:
         o, lay = self.o, self.lay
@@ -212,17 +213,28 @@ class _ExchangeState:
             self.work = dist.all_to_all_single(self.recv_fwd, emb.reshape(-1), output_split_sizes=lay["recv_splits"],
                                                input_split_sizes=lay["send_splits"], group=o._pg, async_op=True)
 
+    def output_destination(self) -> torch.Tensor:
+        """The [B, sum D] tensor finish_forward() unpacks into: the consumer's own buffer (e.g. the static input of a
+        HIP-graph segment: no copy downstream) or a fresh one.  Available before the all-to-all is done, so that the
+        replicated tables' lookup can fill its columns meanwhile."""
+        if self._dest is None:
+            o = self.o
+            buf = o._output_buffer
+            self._dest = (o._alias_output_buffer(self.B) if buf is not None and buf.numel() == self.B * o._D_total
+                          else torch.empty((self.B, o._D_total), dtype=torch.float32, device=self.recv_fwd.device))
+        return self._dest
+
     def finish_forward(self) -> torch.Tensor:
         with label("## alltoall_fwd_wait ##"):
             self.work.wait()
         self.work = None
         lay = self.lay
-        buf = self.o._output_buffer
-        if buf is not None and buf.numel() == self.B * self.o._D_total:
-            # the consumer's own buffer (e.g. the static input of a HIP-graph segment): no copy downstream
+        if self._dest is not None or (self.o._output_buffer is not None
+                                      and self.o._output_buffer.numel() == self.B * self.o._D_total):
+            dest, self._dest = self.output_destination(), None
             return torch.ops.tbe_hip.pooled_exchange_unpack_into(
                 self.recv_fwd, lay["feat_out_col"], lay["feat_src"], lay["feat_slab_col"], lay["slab_offset"],
-                lay["slab_stride"], self.B, self.o._D_total, self.o._vec_ok, 1.0, self.o._alias_output_buffer(self.B))
+                lay["slab_stride"], self.B, self.o._D_total, self.o._vec_ok, 1.0, dest)
         return torch.ops.tbe_hip.pooled_exchange_unpack(
             self.recv_fwd, lay["feat_out_col"], lay["feat_src"], lay["feat_slab_col"], lay["slab_offset"],
             lay["slab_stride"], self.B, self.o._D_total, self.o._vec_ok, 1.0)
@@ -993,6 +1005,7 @@ class ExplicitLookupStep:
         self.dp_rec = None
         self.state: Optional[_ExchangeState] = None
         self._grad: Optional[torch.Tensor] = None
+        self._early_dp = False
         if owner._exchange:
             # order of the HOST calls: lookup kernel, pooled all-to-all, THEN the backward's side-stream sort (6 launches,
             # ~60 us of host time): the all-to-all is on the step's critical path, the sort is not
@@ -1008,6 +1021,14 @@ class ExplicitLookupStep:
                     m.defer_backward_sort = False
             self.state = _ExchangeState(owner, dist_input.batch_size)
             self.state.start_forward(emb)
+            # the replicated tables' lookup does not depend on the exchange: it fills its columns of the destination
+            # while the all-to-all (on its own hardware queue) is in flight, instead of after the wait
+            self._early_dp = owner._dp_module is not None
+            if self._early_dp:
+                v, offs, w = dist_input.dp
+                with label("## tbe_lookup ##"):
+                    _, self.dp_rec = owner._dp_module.lookup_no_autograd(
+                        v, offs, w, into=(self.state.output_destination(), owner._dp_out_off, owner._D_total))
             if can_defer:
                 m.launch_deferred_backward_sort()
             self._out = None
@@ -1022,7 +1043,7 @@ class ExplicitLookupStep:
         """[B_local, sum D] pooled embeddings in the collection's key order, inside the output buffer."""
         o = self.o
         out = self.state.finish_forward() if self.state is not None else self._out
-        if o._dp_module is not None:
+        if o._dp_module is not None and not self._early_dp:
             v, offs, w = self.d.dp
             out, self.dp_rec = o._dp_module.lookup_no_autograd(v, offs, w, into=(out, o._dp_out_off, o._D_total))
         return out
