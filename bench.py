@@ -295,6 +295,10 @@ def main(args):
         init_data_parallel=False)
     shard = model.sharded_modules()[0]
     shard.reset_parameters_sharding_invariant(args.seed)
+    if rehearse and float(os.environ.get("TORCHREC_AMD_REHEARSAL_LINK_US", "0")) > 0 and shard._exchange:
+        from torchrec_amd.distributed._rehearsal import set_link_full_bytes
+
+        set_link_full_bytes(shard._exchange_layout(B_local)["recv_numel"] * 4)  # a half-batch message spins half as long
     if hip_graphs:
         # HIP-graph replay of the collective-free dense segments; captured before DistributedDataParallel
         # wraps the dense modules (distributed/train_pipeline.py explains why)
@@ -304,6 +308,9 @@ def main(args):
         try:
             train_model.capture_hip_graphs(B_local, flat_grads=True, process_group=env.process_group)
         except Exception as e:  # measured run must not die on a capture problem: run the segments eagerly
+            import traceback
+
+            traceback.print_exc(file=sys.stderr)
             failure = f"{type(e).__name__}: {str(e)[:200]}"
             print(f"[bench] HIP-graph capture failed ({failure}); running eagerly", file=sys.stderr, flush=True)
         if world > 1:
@@ -545,6 +552,7 @@ def main(args):
             "vs_baseline": round(value / 5497159.68, 3) if world == 8 and backend == "nccl" else None,
             "dtype": "f32", "data": "synthetic", "hip_graphs": hip_graphs, "hip_graphs_note": graphs_note,
             "explicit_backward_steps": int(getattr(train_model, "explicit_steps", 0)),
+            "half_batch_steps": int(getattr(train_model, "half_batch_steps", 0)),
             "tuned_gemms": tuned,
             "rccl_ranks": dist.get_world_size() if dist.is_initialized() and dist.get_backend() == "nccl" else 0,
             "backend": dist.get_backend() if dist.is_initialized() else None,
@@ -554,7 +562,7 @@ def main(args):
             "env": {k: os.environ[k] for k in ("GPU_MAX_HW_QUEUES", "HSA_ENABLE_IPC_MODE_LEGACY", "TORCHREC_AMD_RW_INPUT_DIST",
                                                "TORCHREC_AMD_PREFETCH_LOOKUP", "TORCHREC_AMD_FUSED_BCE",
                                                "TORCHREC_AMD_REHEARSAL_LINK_US", "TORCHREC_AMD_RCCL_HIGH_PRIORITY",
-                                               "TBE_STREAM_PROBE") if k in os.environ},
+                                               "TBE_STREAM_PROBE", "TORCHREC_AMD_HALF_BATCHES") if k in os.environ},
             "config": {"workload": "DLRM Criteo-1TB shape: 26 tables (177.9M rows, 84.85 GiB fp32, D=128), 13 dense, "
                                    "pooling factor 1, dense 512-256-128, over 1024-1024-512-256-1, fused exact SGD",
                        "global_batch": args.global_batch, "local_batch": B_local,

@@ -109,3 +109,19 @@ def test_bench_one_rank_rehearsal_of_the_multi_gpu_path():
     assert d["checks"]["sort_giveups"] == 0 and d["checks"]["dense_replicas_identical"] is True
     e = _run(env, "--global-batch", "4096", "--hip-graphs", "off", "--tuned-gemms", "off")
     assert e["hip_graphs"] is False and e["tuned_gemms"] is False and e["value"] > 0
+
+
+def test_bench_rehearsal_with_the_exchange_in_two_half_batches():
+    """TORCHREC_AMD_HALF_BATCHES=1: two half-batch all-to-alls each way and two head segments per step, over the one-rank
+    RCCL group (list-form all_to_all on row-range views), with an emulated link time — same training as whole batches up
+    to the summation order (loss = mean of the halves' means, weight gradients = sum of the halves')."""
+    env = {"TORCHREC_AMD_FORCE_EXCHANGE": "1", "TORCHREC_AMD_FORCE_DP": "1", "MASTER_PORT": "29563",
+           "TORCHREC_AMD_REHEARSAL_LINK_US": "50"}
+    whole = _run(dict(env, TORCHREC_AMD_HALF_BATCHES="0"), "--global-batch", "4096")
+    halves = _run(dict(env, TORCHREC_AMD_HALF_BATCHES="1"), "--global-batch", "4096")
+    assert whole["half_batch_steps"] == 0 and halves["half_batch_steps"] == 7 == halves["explicit_backward_steps"]
+    assert halves["checks"]["sort_giveups"] == 0 and halves["checks"]["bounds_check_errors"] == 0
+    for k in ("loss_first", "loss_last"):
+        assert abs(whole["checks"][k] - halves["checks"][k]) <= 2e-4 * abs(whole["checks"][k]), (k, whole["checks"], halves["checks"])
+    for k in ("dense", "embedding"):
+        assert _close(whole["checks"]["param_checksum"][k], halves["checks"]["param_checksum"][k], 2e-6), k

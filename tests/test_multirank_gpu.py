@@ -37,18 +37,10 @@ class _Done:
 
 
 def _stage_a2a_through_host():
-    real = dist.all_to_all_single
+    """gloo has no device all-to-all: the package's rehearsal plumbing stages both forms through the host."""
+    from torchrec_amd.distributed._rehearsal import stage_all_to_all_through_host
 
-    def a2a(output, input, output_split_sizes=None, input_split_sizes=None, group=None, async_op=False):
-        if not input.is_cuda:
-            return real(output, input, output_split_sizes, input_split_sizes, group=group, async_op=async_op)
-        torch.cuda.current_stream().synchronize()
-        o = torch.empty(output.shape, dtype=output.dtype)
-        real(o, input.cpu().contiguous(), output_split_sizes, input_split_sizes, group=group)
-        output.copy_(o)
-        return _Done() if async_op else None
-
-    dist.all_to_all_single = a2a
+    stage_all_to_all_through_host()
 
 
 def _data(W, fixed_len, weighted, seed=11, max_len=3):
@@ -396,7 +388,7 @@ def _e2e_batches(W):
     return out
 
 
-def _e2e_model(env, dev, dp_max_rows, graph_batch=0, flat=False, seed=0):
+def _e2e_model(env, dev, dp_max_rows, graph_batch=0, flat=False, seed=0, halves=False):
     from torchrec_amd.distributed.embeddingbag import EmbeddingBagCollectionSharder
     from torchrec_amd.distributed.model_parallel import DistributedModelParallel
     from torchrec_amd.distributed.planner import EmbeddingShardingPlanner, Topology
@@ -416,7 +408,7 @@ def _e2e_model(env, dev, dp_max_rows, graph_batch=0, flat=False, seed=0):
                                                                       dp_max_rows=dp_max_rows),
                                      init_data_parallel=not graph_batch)
     if graph_batch:  # HIP-graph segments must be captured BEFORE DistributedDataParallel wraps the dense modules
-        tm.capture_hip_graphs(graph_batch, flat_grads=flat, process_group=env.process_group)
+        tm.capture_hip_graphs(graph_batch, flat_grads=flat, process_group=env.process_group, half_batches=halves)
         model.init_data_parallel()
     opt = CombinedOptimizer([model.fused_optimizer,
                              # flat mode: the one-kernel SGD over the flat buffers, as bench.py builds it (optim/flat.py)
@@ -475,9 +467,13 @@ def _e2e_worker(rank, W, port, ret, hip_graphs=False):
         _stage_a2a_through_host()
         from torchrec_amd.distributed.types import ShardingEnv
 
+        halves = hip_graphs == "flat-halves"  # the exchange in two half-batches (capture_hip_graphs(half_batches=True))
+        if halves:
+            hip_graphs = "flat"
         keys, model, opt = _e2e_model(ShardingEnv.from_process_group(dist.group.WORLD), dev, dp_max_rows=10,
                                       graph_batch=E_B if hip_graphs else 0, flat=(hip_graphs == "flat"),
-                                      seed=0 if rank == 0 else 77)  # ranks > 0 must receive rank 0's dense weights
+                                      seed=0 if rank == 0 else 77,  # ranks > 0 must receive rank 0's dense weights
+                                      halves=halves)
         if hip_graphs == "flat":
             assert len(model.module.flat_grad_parameters()) > 0
         _e2e_init_tables(model)
@@ -490,18 +486,20 @@ def _e2e_worker(rank, W, port, ret, hip_graphs=False):
         assert (model.module._graphs is not None) == bool(hip_graphs)
         # flat-gradient graph mode runs forward AND backward by hand (DLRMTrain._explicit_step), no autograd engine
         assert (getattr(model.module, "explicit_steps", 0) == E_STEPS) == (hip_graphs == "flat")
+        assert getattr(model.module, "half_batch_steps", 0) == (E_STEPS if halves else 0)
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("hip_graphs", [False, True, "flat"])
+@pytest.mark.parametrize("hip_graphs", [False, True, "flat", "flat-halves"])
 def test_dlrm_train_world2_on_one_gpu_matches_world1(hip_graphs):
     """hip_graphs=True: the dense segments replay from HIP graphs under DistributedDataParallel — captured
     BEFORE the DDP wrap (capturing a backward graph over DDP-managed parameters crashes in
     hipStreamEndCapture on this stack; the pipeline's lazy capture is therefore declined under DDP).
     "flat": the graphed segments' gradients additionally travel through one flat all-reduced buffer instead
     of DDP (models/dlrm.py capture_hip_graphs(flat_grads=True)); ranks start from different dense weights
-    and must end identical (the rank-0 broadcast DDP would have done)."""
+    and must end identical (the rank-0 broadcast DDP would have done).
+    "flat-halves": the same with the pooled exchange and the head segment in two half-batches per step."""
     W = 2
     ret = ResultStore()
     mp.spawn(_e2e_worker, args=(W, _free_port(), ret, hip_graphs), nprocs=W, join=True)

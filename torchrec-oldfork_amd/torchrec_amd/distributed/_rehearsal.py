@@ -38,20 +38,43 @@ def stage_all_to_all_through_host() -> None:
         return _Done() if async_op else None
 
     dist.all_to_all_single = all_to_all_single
+    real_list = dist.all_to_all
+
+    def all_to_all(output_tensor_list, input_tensor_list, group=None, async_op=False):
+        """The list form (pieces that are views, e.g. the half-batch exchange) through ONE host all_to_all_single."""
+        if not input_tensor_list or not input_tensor_list[0].is_cuda:
+            return real_list(output_tensor_list, input_tensor_list, group=group, async_op=async_op)
+        torch.cuda.current_stream(input_tensor_list[0].device).synchronize()
+        dtype = input_tensor_list[0].dtype
+        host_in = torch.cat([t.reshape(-1).cpu() for t in input_tensor_list])
+        host_out = torch.empty(sum(t.numel() for t in output_tensor_list), dtype=dtype)
+        real(host_out, host_in, [t.numel() for t in output_tensor_list], [t.numel() for t in input_tensor_list], group=group)
+        for t, piece in zip(output_tensor_list, host_out.split([t.numel() for t in output_tensor_list])):
+            t.copy_(piece.view(t.shape))
+        return _Done() if async_op else None
+
+    dist.all_to_all = all_to_all
 
 
 _link_state = {}
 
 
-def emulate_link_time(fwd_us: float) -> None:
+def set_link_full_bytes(nbytes: int) -> None:
+    """The message size the emulated link time stands for (see emulate_link_time)."""
+    _link_state["full_bytes"] = int(nbytes)
+
+
+def emulate_link_time(fwd_us: float, full_bytes: int = 0) -> None:
     """One-rank rehearsal: make every device `all_to_all_single` take at least `fwd_us` microseconds on the GPU timeline,
     as a transfer over xGMI would (the one-rank RCCL all-to-all is a local copy at HBM speed: 109 MB in 44 us, where 7
     links move a rank's 25 MB per peer in ~250 us).  A spin kernel (`torch.cuda._sleep`, one wavefront) runs on a
     dedicated stream in front of the collective, which is issued from that stream: the collective's own stream then waits
     for the spin, consumers wait for the collective as always, the compute stream is never touched.  Calibrated once.
+    `full_bytes`: the message size `fwd_us` stands for; a smaller message (one half of a half-batch exchange) spins
+    proportionally shorter.  0 = every message takes `fwd_us`.
     Measurement plumbing for bench.py (TORCHREC_AMD_REHEARSAL_LINK_US); never on a real multi-GPU run."""
     global _real_all_to_all_single
-    if fwd_us <= 0 or _link_state:
+    if fwd_us <= 0 or "stream" in _link_state:
         return
     dev = torch.device("cuda", torch.cuda.current_device())
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -62,21 +85,38 @@ def emulate_link_time(fwd_us: float) -> None:
     b.record()
     b.synchronize()
     cycles_per_us = 10_000_000 / (a.elapsed_time(b) * 1e3)
-    _link_state.update(stream=side_stream(dev), cycles=int(fwd_us * cycles_per_us), us=fwd_us)
+    _link_state.update(full_bytes=int(full_bytes or _link_state.get("full_bytes", 0)), stream=side_stream(dev), cycles=int(fwd_us * cycles_per_us), us=fwd_us)
     real = dist.all_to_all_single
 
     def all_to_all_single(output, input, output_split_sizes=None, input_split_sizes=None, group=None, async_op=False):
         if not input.is_cuda or input.numel() * input.element_size() < (1 << 20):  # ids: small, latency only
             return real(output, input, output_split_sizes, input_split_sizes, group=group, async_op=async_op)
+        return behind_link(lambda: real(output, input, output_split_sizes, input_split_sizes, group=group, async_op=async_op),
+                           [output, input], input.numel() * input.element_size(), async_op)
+
+    def behind_link(issue, tensors, nbytes, async_op):
         link = _link_state["stream"]
         link.wait_stream(torch.cuda.current_stream())
+        fb = _link_state.get("full_bytes", 0)
+        frac = min(1.0, nbytes / fb) if fb > 0 else 1.0
         with torch.cuda.stream(link):
-            torch.cuda._sleep(_link_state["cycles"])
-            work = real(output, input, output_split_sizes, input_split_sizes, group=group, async_op=async_op)
-        for t in (output, input):
+            torch.cuda._sleep(max(int(_link_state["cycles"] * frac), 1))
+            work = issue()
+        for t in tensors:
             t.record_stream(link)
         if not async_op:
             torch.cuda.current_stream().wait_stream(link)
         return work
+
+    real_list = dist.all_to_all
+
+    def all_to_all(output_tensor_list, input_tensor_list, group=None, async_op=False):
+        nbytes = sum(t.numel() * t.element_size() for t in input_tensor_list)
+        if not input_tensor_list or not input_tensor_list[0].is_cuda or nbytes < (1 << 20):
+            return real_list(output_tensor_list, input_tensor_list, group=group, async_op=async_op)
+        return behind_link(lambda: real_list(output_tensor_list, input_tensor_list, group=group, async_op=async_op),
+                           list(output_tensor_list) + list(input_tensor_list), nbytes, async_op)
+
+    dist.all_to_all = all_to_all
 
     dist.all_to_all_single = all_to_all_single

@@ -205,6 +205,8 @@ class _ExchangeState:
         self.grad_recv: Optional[torch.Tensor] = None
         self.bwd_work = None
         self._dest: Optional[torch.Tensor] = None
+        self._half_bwd_work: List[Any] = []
+        self._half_send_keepalive: List[torch.Tensor] = []
 
     def start_forward(self, emb: torch.Tensor) -> None:
         o, lay = self.o, self.lay
@@ -257,10 +259,69 @@ class _ExchangeState:
 
     def finish_backward(self) -> torch.Tensor:
         with label("## alltoall_bwd_wait ##"):
-            self.bwd_work.wait()
+            if self.bwd_work is not None:
+                self.bwd_work.wait()
+            for w in self._half_bwd_work:
+                w.wait()
         self.bwd_work = None
+        self._half_bwd_work = []
         self._send_keepalive = None
         return self.grad_recv.view(self.o._world_size * self.B, self.o._D_local)
+
+    # ---- the same exchange in two half-batches (rows [0, B/2) and [B/2, B) of every rank's local batch) -------------
+    # Each half is its own all-to-all (list form: the pieces are row ranges of the slabs, contiguous but not adjacent),
+    # laid out exactly like a batch of B/2: unpack / pack run with the B/2 layout on the half's rows.  The caller runs
+    # half 0's dense work while half 1's embeddings are on the links, and half 1's while half 0's gradients are
+    # (models/dlrm.py explicit step): on point-to-point xGMI links the exchange is otherwise exposed.
+    def start_forward_halves(self, emb: torch.Tensor) -> None:
+        o, W, B = self.o, self.o._world_size, self.B
+        if B % 2:
+            raise RuntimeError("half-batch exchange: the per-rank batch must be even")
+        Bh = B // 2
+        layh = self.lay_half = o._exchange_layout(Bh)
+        src = emb.view(W, B, o._D_local)
+        self._half_recv, self._half_work = [], []
+        for h in range(2):
+            recv = torch.empty(layh["recv_numel"], dtype=torch.float32, device=emb.device)
+            with label("## alltoall_fwd_single ##"):  # comm_ops.py:489
+                work = dist.all_to_all(list(recv.split(layh["recv_splits"])), [src[d, h * Bh:(h + 1) * Bh] for d in range(W)],
+                                       group=o._pg, async_op=True)
+            self._half_recv.append(recv)
+            self._half_work.append(work)
+        self.recv_fwd = self._half_recv[0]  # (device of the destination)
+        self._emb_keepalive = emb
+
+    def finish_forward_half(self, h: int) -> torch.Tensor:
+        """Waits for half h and unpacks it into rows [h B/2, (h + 1) B/2) of the destination; returns those rows."""
+        with label("## alltoall_fwd_wait ##"):
+            self._half_work[h].wait()
+        self._half_work[h] = None
+        layh, Bh, o = self.lay_half, self.B // 2, self.o
+        rows = self.output_destination()[h * Bh:(h + 1) * Bh]
+        torch.ops.tbe_hip.pooled_exchange_unpack_into(
+            self._half_recv[h], layh["feat_out_col"], layh["feat_src"], layh["feat_slab_col"], layh["slab_offset"],
+            layh["slab_stride"], Bh, o._D_total, o._vec_ok, 1.0, rows)
+        self._half_recv[h] = None
+        if h == 1:
+            self._emb_keepalive = None
+        return rows
+
+    def start_backward_half(self, h: int, grad_rows: torch.Tensor) -> None:
+        """grad_rows: [B/2, sum D] gradient of rows [h B/2, (h + 1) B/2) of the pooled output, contiguous."""
+        o, W, B = self.o, self.o._world_size, self.B
+        Bh, layh = B // 2, self.lay_half
+        scale = 1.0 / W if GRADIENT_DIVISION else 1.0
+        send = torch.ops.tbe_hip.pooled_exchange_pack(
+            grad_rows, layh["feat_out_col"], layh["feat_src"], layh["feat_slab_col"], layh["slab_offset"],
+            layh["slab_stride"], layh["recv_numel"], o._vec_ok, scale)
+        if self.grad_recv is None:
+            self.grad_recv = torch.empty(self.lay["send_numel"], dtype=torch.float32, device=grad_rows.device)
+        dst = self.grad_recv.view(W, B, o._D_local)
+        with label("## alltoall_bwd_single ##"):  # comm_ops.py:591
+            work = dist.all_to_all([dst[s, h * Bh:(h + 1) * Bh] for s in range(W)], list(send.split(layh["recv_splits"])),
+                                   group=o._pg, async_op=True)
+        self._half_bwd_work.append(work)
+        self._half_send_keepalive.append(send)
 
 
 class _OutputAwaitable(LazyAwaitable):
@@ -449,6 +510,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
         self.sharded_tensor_state = True
         self._kjt_cache: Dict[Tuple, Any] = {}
         self._output_buffer: Optional[torch.Tensor] = None  # see set_output_buffer
+        self.half_batch_exchange = False  # see set_half_batch_exchange
         # ---- local tables + TBE ----------------------------------------------------------------
         self._local_tables: List[_LocalTable] = []
         local_table_index: Dict[int, int] = {}
@@ -529,6 +591,12 @@ class ShardedEmbeddingBagCollection(nn.Module):
         segment, so that the segment reads the embeddings in place.  The caller owns the aliasing: the
         output of step i is overwritten by step i + 1."""
         self._output_buffer = buf
+
+    def set_half_batch_exchange(self, on: bool) -> None:
+        """compute_explicit() then exchanges the pooled embeddings (and their gradients) as two half-batches
+        (ExplicitLookupStep.finish_half / start_backward_half): the owner of the step interleaves the halves' dense work
+        with the other half's exchange."""
+        self.half_batch_exchange = bool(on)
 
     def _alias_output_buffer(self, B: int) -> torch.Tensor:
         """A fresh [B, sum D] tensor over the output buffer's storage that is NOT an autograd view of it
@@ -989,7 +1057,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
         the fused backward.  Check explicit_step_supported() first."""
         if not self.explicit_step_supported(dist_input.batch_size):
             raise RuntimeError("compute_explicit: not available for this configuration (explicit_step_supported())")
-        return ExplicitLookupStep(self, dist_input)
+        return ExplicitLookupStep(self, dist_input, halves=self.half_batch_exchange)
 
     def forward(self, features: KeyedJaggedTensor) -> Awaitable[KeyedTensor]:
         return self.compute_and_output_dist(self.input_dist(features).wait())
@@ -1000,8 +1068,9 @@ class ExplicitLookupStep:
     With the exchange: lookup in all-to-all layout -> pooled all-to-all -> unpack into the output buffer; without
     (one rank): the lookup writes its column blocks of the output buffer directly."""
 
-    def __init__(self, owner: "ShardedEmbeddingBagCollection", dist_input: SparseFeaturesDist) -> None:
+    def __init__(self, owner: "ShardedEmbeddingBagCollection", dist_input: SparseFeaturesDist, halves: bool = False) -> None:
         self.o, self.d = owner, dist_input
+        self.halves = bool(halves and owner._exchange)  # two half-batch exchanges (finish_half / start_backward_half)
         self.dp_rec = None
         self.state: Optional[_ExchangeState] = None
         self._grad: Optional[torch.Tensor] = None
@@ -1020,7 +1089,10 @@ class ExplicitLookupStep:
                 if can_defer:
                     m.defer_backward_sort = False
             self.state = _ExchangeState(owner, dist_input.batch_size)
-            self.state.start_forward(emb)
+            if self.halves:
+                self.state.start_forward_halves(emb)
+            else:
+                self.state.start_forward(emb)
             # the replicated tables' lookup does not depend on the exchange: it fills its columns of the destination
             # while the all-to-all (on its own hardware queue) is in flight, instead of after the wait
             self._early_dp = owner._dp_module is not None
@@ -1048,14 +1120,29 @@ class ExplicitLookupStep:
             out, self.dp_rec = o._dp_module.lookup_no_autograd(v, offs, w, into=(out, o._dp_out_off, o._D_total))
         return out
 
+    def finish_half(self, h: int) -> torch.Tensor:
+        """Half-batch mode: rows [h B/2, (h + 1) B/2) of the pooled output, complete (the replicated tables' columns were
+        filled for the whole batch while the exchange was in flight)."""
+        return self.state.finish_forward_half(h)
+
+    def start_backward_half(self, h: int, grad_rows: torch.Tensor, grad_out: Optional[torch.Tensor] = None) -> None:
+        """Half-batch mode: packs and starts the gradient all-to-all of half h.  With the LAST half pass `grad_out`, the
+        whole [B_local, sum D] gradient (both halves written): the replicated tables' backward runs on it meanwhile."""
+        self.state.start_backward_half(h, grad_rows)
+        if grad_out is not None:
+            self._dp_backward(grad_out)
+
     def start_backward(self, grad_out: torch.Tensor) -> None:
         """grad_out: [B_local, sum D], contiguous.  Packs and starts the gradient all-to-all (if any), and runs the
         replicated tables' backward (their dense gradient lands in `.grad` of the module's weights) meanwhile."""
-        o = self.o
         if self.state is not None:
             self.state.start_backward(grad_out)
         else:
             self._grad = grad_out
+        self._dp_backward(grad_out)
+
+    def _dp_backward(self, grad_out: torch.Tensor) -> None:
+        o = self.o
         if self.dp_rec is not None:
             w = o._dp_module.weights
             g = o._dp_module.backward_no_autograd(self.dp_rec, grad_out)

@@ -192,6 +192,15 @@ class GraphedSegment(nn.Module):
         self._sink_tables = []  # (device segment table, its rows, the source tensors kept alive)
         sink_table = (torch.zeros((len(param_grad_sinks), 4), dtype=torch.int64, device=param_grad_sinks[0].device)
                       if param_grad_sinks else None)  # ordinary allocation: NOT in the graphs' pool (see write_sinks)
+        if defer_wgrad and self.static_inputs[0].is_cuda:
+            # the deferred weight gradients run batched GEMMs (modules/mlp.py compute_partials) that the warm-up never
+            # ran: the BLAS handle of this stream must exist before the capture (creating it inside one fails with
+            # HIPBLAS_STATUS_INTERNAL_ERROR and invalidates the capture)
+            with torch.cuda.stream(self._stream):
+                probe = torch.zeros(2, 8, 8, device=self.static_inputs[0].device)
+                torch.bmm(probe.transpose(1, 2), probe)
+                torch.mm(probe[0].t(), probe[1])
+                del probe
         self._stream.synchronize()
         stash = []
         with_partials = bool(defer_wgrad and param_grad_sinks is not None)

@@ -57,6 +57,14 @@ _SORT_PLACEMENT = os.environ.get("TORCHREC_AMD_SORT_PLACEMENT", "lookup")
 _EXPLICIT_STEP = os.environ.get("TORCHREC_AMD_EXPLICIT_STEP", "1") != "0"
 # flat mode: capture the head segment's weight-gradient GEMMs into a second backward graph (0: one graph as before)
 _DEFER_WGRAD = os.environ.get("TORCHREC_AMD_DEFER_WGRAD", "1") != "0"
+# Two half-batches per step when the pooled embeddings cross links (DLRMTrain.capture_hip_graphs(half_batches=)):
+# "auto" = on for per-rank batches of at least this many samples — N = 2 at the global batch of 65 536, where the exchange
+# takes ~1.5 ms per pass over the one link pair and only half of the forward one stays exposed.  Measured with emulated
+# link times: 7.01 -> 6.30 ms per step at 32 768 per rank; a tie at 16 384 (3.40 / 3.38) and a loss at 8192
+# (1.86 -> 2.01): two half-size passes cost 0.2 - 0.3 ms more kernel time (GEMMs at half M, kernels at their latency floor).
+# "1" / "0" force it.
+_HALF_BATCHES = os.environ.get("TORCHREC_AMD_HALF_BATCHES", "auto")
+_HALF_BATCH_MIN = int(os.environ.get("TORCHREC_AMD_HALF_BATCH_MIN", "32768"))
 
 
 def _pad64(n: int) -> int:
@@ -91,7 +99,7 @@ class _FusedDotInteraction(torch.autograd.Function):
     rows (lda = S, K = D + P; tools/gemm_probe.py).  Values and shapes are those of the dense result."""
 
     @staticmethod
-    def forward(ctx, dense, sparse, pad_rows=False):
+    def forward(ctx, dense, sparse, pad_rows=False, grad_sinks=None):
         from fbgemm_gpu import _lib
         from fbgemm_gpu._lib import check, ptr, stream_ptr
 
@@ -108,6 +116,9 @@ class _FusedDotInteraction(torch.autograd.Function):
                                                                stream_ptr(dense.device)),
                   "tbe_dlrm_interaction_forward_f32")
         ctx.save_for_backward(dense, sparse)
+        # (d dense, d sparse) buffers of the caller instead of fresh allocations: a captured backward then writes e.g. its
+        # half of a whole-batch gradient buffer in place (DLRMTrain.capture_hip_graphs(half_batches=True))
+        ctx.grad_sinks = grad_sinks
         return buf if stride == width else buf[:, :width]
 
     @staticmethod
@@ -122,12 +133,18 @@ class _FusedDotInteraction(torch.autograd.Function):
             raise RuntimeError(f"dot interaction backward: grad_out {tuple(grad_out.shape)} has the wrong shape")
         if grad_out.dtype != torch.float32 or grad_out.stride(1) != 1 or grad_out.stride(0) < width:
             grad_out = grad_out.float().contiguous()  # padded rows (stride >= width) are read in place
-        gd, gs = torch.empty_like(dense), torch.empty_like(sparse)
+        if ctx.grad_sinks is not None:
+            gd, gs = ctx.grad_sinks
+            if (gd.shape != dense.shape or gs.shape != sparse.shape or not gd.is_contiguous() or not gs.is_contiguous()
+                    or gd.dtype != torch.float32 or gs.dtype != torch.float32 or gd.device != dense.device):
+                raise RuntimeError("dot interaction backward: gradient sinks do not match the inputs")
+        else:
+            gd, gs = torch.empty_like(dense), torch.empty_like(sparse)
         with torch.cuda.device(dense.device):
             check(_lib.load().tbe_dlrm_interaction_backward_f32(ptr(dense), ptr(sparse), ptr(grad_out), grad_out.stride(0),
                                                                 B, F, D, ptr(gd), ptr(gs), stream_ptr(dense.device)),
                   "tbe_dlrm_interaction_backward_f32")
-        return gd, gs, None
+        return gd, gs, None, None
 
 
 def _fused_interaction_ok(dense: torch.Tensor, sparse: torch.Tensor) -> bool:
@@ -148,13 +165,14 @@ class InteractionArch(nn.Module):
         # MI355X it buys nothing — the recorded GEMM choices run the 479-wide layer as fast at lda = 479 as at 480
         # (0.481 / 0.464 / 0.439 ms vs 0.479 / 0.464 / 0.445 ms) and the interaction kernels are not store-bound.
         self.pad_rows = os.environ.get("TORCHREC_AMD_PAD_INTERACTION", "0") == "1"
+        self.grad_sinks = None  # (d dense, d sparse) buffers the fused backward writes into; read at forward time
         self.register_buffer("triu_indices", torch.triu_indices(self.F + 1, self.F + 1, offset=1), persistent=False)
 
     def forward(self, dense_features: torch.Tensor, sparse_features: torch.Tensor) -> torch.Tensor:
         if self.F <= 0:
             return dense_features
         if self.fused and _fused_interaction_ok(dense_features, sparse_features):
-            return _FusedDotInteraction.apply(dense_features, sparse_features, self.pad_rows)
+            return _FusedDotInteraction.apply(dense_features, sparse_features, self.pad_rows, self.grad_sinks)
         # generic shapes: the reference's formulation on torch ops
         combined = torch.cat((dense_features.unsqueeze(1), sparse_features), dim=1)
         interactions = torch.bmm(combined, combined.transpose(1, 2))
@@ -272,7 +290,8 @@ class DLRMTrain(nn.Module):
         self.loss_fn = nn.BCEWithLogitsLoss()
         self._graphs = None  # (batch size, bottom-MLP segment, head segment)
 
-    def capture_hip_graphs(self, batch_size: int, flat_grads: bool = False, process_group=None) -> None:
+    def capture_hip_graphs(self, batch_size: int, flat_grads: bool = False, process_group=None,
+                           half_batches: Optional[bool] = None) -> None:
         """Captures the two collective-free dense segments of a train step — bottom MLP; interaction
         + top MLP + loss — as HIP graphs for this per-rank batch size (distributed/hip_graph.py).
         Steps with another batch size, eval mode or no_grad run eagerly as before.
@@ -315,12 +334,39 @@ class DLRMTrain(nn.Module):
                             view.copy_(q)
                             q.data = view
                             off += q.numel()
+        ebc = m.sparse_arch.embedding_bag_collection
+        ebc = getattr(ebc, "sharded", ebc)  # a train pipeline may have wrapped it
+        if half_batches is None:
+            half_batches = _HALF_BATCHES == "1" or (_HALF_BATCHES == "auto" and B >= _HALF_BATCH_MIN)
+        halves = bool(half_batches and flat_grads and B % 2 == 0 and getattr(ebc, "_exchange", False)
+                      and hasattr(ebc, "set_half_batch_exchange") and _EXPLICIT_STEP)
         g_dense = GraphedSegment(m.dense_arch, [torch.randn(B, dense_in, device=dev)])
-        g_head = GraphedSegment(
-            head, [g_dense.static_outputs[0].detach().requires_grad_(True),
-                   torch.randn(B, F, D, device=dev).requires_grad_(True),
-                   torch.randint(0, 2, (B,), device=dev)],  # int64, as the data loader delivers them
-            input_buffers=[g_dense.static_outputs[0], None, None], pool=g_dense._pool)
+        if halves:
+            # whole-batch buffers the two head segments share by halves: pooled embeddings (the collection's output
+            # buffer), labels, and the gradients w.r.t. the bottom-MLP output / the pooled embeddings
+            Bh = B // 2
+            Dd = g_dense.static_outputs[0].shape[1]
+            half = {"pooled": torch.zeros(B, F, D, device=dev), "labels": torch.zeros(B, dtype=torch.int64, device=dev),
+                    "gd": torch.zeros(B, Dd, device=dev), "gs": torch.zeros(B, F, D, device=dev), "Bh": Bh}
+            heads = []
+            for h in range(2):
+                rows = slice(h * Bh, (h + 1) * Bh)
+                m.inter_arch.grad_sinks = (half["gd"][rows], half["gs"][rows])
+                try:
+                    heads.append(GraphedSegment(
+                        head, [g_dense.static_outputs[0][rows].detach().requires_grad_(True),
+                               half["pooled"][rows].detach().requires_grad_(True), half["labels"][rows]],
+                        input_buffers=[g_dense.static_outputs[0][rows], half["pooled"][rows], half["labels"][rows]],
+                        pool=g_dense._pool))
+                finally:
+                    m.inter_arch.grad_sinks = None
+            g_head = heads[1]
+        else:
+            g_head = GraphedSegment(
+                head, [g_dense.static_outputs[0].detach().requires_grad_(True),
+                       torch.randn(B, F, D, device=dev).requires_grad_(True),
+                       torch.randint(0, 2, (B,), device=dev)],  # int64, as the data loader delivers them
+                input_buffers=[g_dense.static_outputs[0], None, None], pool=g_dense._pool)
         head_sinks = dense_sinks = None
         scale = 1.0
         if flat_grads:
@@ -364,16 +410,40 @@ class DLRMTrain(nn.Module):
             g_dense.after_backward = dense_done
             object.__setattr__(self, "_flat_dense", state)
         # the embedding collection writes its pooled output straight into the head segment's static input
-        ebc = m.sparse_arch.embedding_bag_collection
-        ebc = getattr(ebc, "sharded", ebc)  # a train pipeline may have wrapped it
-        if hasattr(ebc, "set_output_buffer"):
-            ebc.set_output_buffer(g_head.static_input(1).detach())
-        # flat mode: the head's weight gradients go into a second graph that the explicit step replays after it has
-        # started the embedding-gradient all-to-all (modules/mlp.py _DeferredWgrad)
-        g_head.capture_backward(param_grad_sinks=head_sinks, sink_scale=scale, defer_wgrad=flat_grads and _DEFER_WGRAD)
-        # the head's gradient w.r.t. the bottom-MLP output doubles as the bottom segment's grad_output buffer
-        g_dense.capture_backward([g_head.static_grad_inputs[0]], param_grad_sinks=dense_sinks, sink_scale=scale,
-                                 defer_wgrad=flat_grads and _DEFER_WGRAD)
+        if hasattr(ebc, "set_half_batch_exchange"):
+            ebc.set_half_batch_exchange(halves)
+        if halves:
+            ebc.set_output_buffer(half["pooled"])
+            # half 0's parameter gradients go to a buffer of their own and are added to half 1's (which sit in the flat
+            # buffer) by one launch after both weight-gradient graphs
+            tmp = torch.zeros(n_head, dtype=torch.float32, device=dev)
+            tmp_sinks, off = [], 0
+            for q in g_head._params:
+                tmp_sinks.append(tmp[off:off + q.numel()].view_as(q))
+                off += q.numel()
+            half["tmp"], half["n_head_used"] = tmp, off
+            for h, gh in enumerate(heads):
+                gh.capture_backward(param_grad_sinks=tmp_sinks if h == 0 else head_sinks, sink_scale=scale,
+                                    defer_wgrad=_DEFER_WGRAD)
+                rows = slice(h * Bh, (h + 1) * Bh)
+                if (gh.static_grad_inputs[0].data_ptr() != half["gd"][rows].data_ptr()
+                        or gh.static_grad_inputs[1].data_ptr() != half["gs"][rows].data_ptr()):
+                    raise RuntimeError("capture_hip_graphs(half_batches=True): the head segment's input gradients did not land "
+                                       "in the shared whole-batch buffers (is the fused dot interaction in use?)")
+            heads[1].after_backward = heads[0].after_backward = None
+            half["heads"], half["reduce_head"] = heads, reduce_head
+            g_dense.capture_backward([half["gd"]], param_grad_sinks=dense_sinks, sink_scale=scale, defer_wgrad=_DEFER_WGRAD)
+            object.__setattr__(self, "_half", half)
+        else:
+            if hasattr(ebc, "set_output_buffer"):
+                ebc.set_output_buffer(g_head.static_input(1).detach())
+            # flat mode: the head's weight gradients go into a second graph that the explicit step replays after it has
+            # started the embedding-gradient all-to-all (modules/mlp.py _DeferredWgrad)
+            g_head.capture_backward(param_grad_sinks=head_sinks, sink_scale=scale, defer_wgrad=flat_grads and _DEFER_WGRAD)
+            # the head's gradient w.r.t. the bottom-MLP output doubles as the bottom segment's grad_output buffer
+            g_dense.capture_backward([g_head.static_grad_inputs[0]], param_grad_sinks=dense_sinks, sink_scale=scale,
+                                     defer_wgrad=flat_grads and _DEFER_WGRAD)
+            object.__setattr__(self, "_half", None)
         object.__setattr__(self, "_graphs", (B, g_dense, g_head))  # not sub-modules: state_dict keys unchanged
         # the explicit step fills d(loss) = 1 into the NEW head segment's grad-output buffer (zeros after capture)
         object.__setattr__(self, "_loss_grad_ready", False)
@@ -504,6 +574,12 @@ class DLRMTrain(nn.Module):
         if step is None:
             return None
         B = g_dense.static_inputs[0].shape[0]
+        half = getattr(self, "_half", None)
+        if half is not None:
+            if not getattr(step, "halves", False):
+                raise RuntimeError("DLRMTrain: the head segments were captured for half-batch exchanges, the collection did "
+                                   "not start one")
+            return self._explicit_step_halves(batch, step, g_dense, half, B)
         with torch.no_grad():
             # bottom MLP (graph) while the pooled all-to-all is in flight
             if batch.dense_features.data_ptr() != g_dense.static_inputs[0].data_ptr():
@@ -546,6 +622,55 @@ class DLRMTrain(nn.Module):
         object.__setattr__(self, "explicit_steps", getattr(self, "explicit_steps", 0) + 1)  # for tests / bench.py's line
         return loss.detach(), (loss.detach(), logits.detach(), batch.labels.detach())
 
+    def _explicit_step_halves(self, batch, step, g_dense, half, B: int):
+        """The explicit step with the exchange in two half-batches (capture_hip_graphs(half_batches=True)):
+
+            lookup (whole batch) -> all-to-all half 0, half 1 -> bottom MLP
+            half 0: wait, unpack, head forward, head backward (input gradients), pack, gradient all-to-all 0
+            half 1: the same — its embeddings crossed the links during half 0's work, half 0's gradients cross during this
+            weight gradients of both halves, bottom-MLP backward (gradient all-to-all 1 in flight), embedding backward."""
+        heads, Bh = half["heads"], half["Bh"]
+        with torch.no_grad():
+            if batch.dense_features.data_ptr() != g_dense.static_inputs[0].data_ptr():
+                g_dense.static_inputs[0].copy_(batch.dense_features)
+            g_dense.fwd_graph.replay()
+            half["labels"].copy_(batch.labels)
+            if not getattr(self, "_loss_grad_ready", False):
+                for gh in heads:
+                    gh.static_grad_outputs[0].fill_(0.5)  # loss = (mean of half 0 + mean of half 1) / 2
+                object.__setattr__(self, "_loss_grad_ready", True)
+            gs_all = half["gs"].view(B, -1)
+            between = getattr(self, "_between", None)
+            with label("## backward ##"):  # train_pipeline.py:546 (the halves' forwards are inside: they alternate)
+                for h, gh in enumerate(heads):
+                    step.finish_half(h)  # into the rows of the pooled buffer this segment reads
+                    gh.fwd_graph.replay()
+                    if h == 0 and between is not None:
+                        between()
+                    gh.bwd_graph.replay()  # ends with the gradients of this half's pooled embeddings / bottom-MLP output
+                    step.start_backward_half(h, gs_all[h * Bh:(h + 1) * Bh], grad_out=gs_all if h == 1 else None)
+                for gh in heads:
+                    if getattr(gh, "bwd_graph2", None) is not None:
+                        gh.bwd_graph2.replay()  # weight gradients, while the gradient all-to-alls are in flight
+                n = half["n_head_used"]
+                st = self._flat_dense
+                st["flat"][:n].add_(half["tmp"][:n])
+                half["reduce_head"]()  # all-reduce of the head's slice of the flat gradient
+                g_dense.bwd_graph.replay()
+                if getattr(g_dense, "bwd_graph2", None) is not None:
+                    g_dense.bwd_graph2.replay()
+                if g_dense.after_backward is not None:
+                    g_dense.after_backward()
+                if st["fired"] == 2:
+                    self._start_rest_reduce(st)
+                step.finish_backward()
+            loss = (heads[0].static_outputs[0] + heads[1].static_outputs[0]) * 0.5
+            logits = torch.cat([heads[0].static_outputs[1], heads[1].static_outputs[1]])
+        object.__setattr__(self, "_backward_done", True)
+        object.__setattr__(self, "explicit_steps", getattr(self, "explicit_steps", 0) + 1)
+        object.__setattr__(self, "half_batch_steps", getattr(self, "half_batch_steps", 0) + 1)  # for tests / bench.py's line
+        return loss.detach(), (loss.detach(), logits.detach(), batch.labels.detach())
+
     def forward(self, batch) -> Tuple[torch.Tensor, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
         g = self._graphs
         if (g is not None and self.training and torch.is_grad_enabled()
@@ -559,6 +684,9 @@ class DLRMTrain(nn.Module):
                 object.__setattr__(self, "_prefetch", None)
                 if out is not None:
                     return out
+            if getattr(self, "_half", None) is not None:
+                raise RuntimeError("DLRMTrain: graphs captured with half_batches=True serve the explicit step only (run the "
+                                   "model under TrainPipelineSparseDist, or capture with half_batches=False)")
             defer, launch = _sort_hooks(self.model.sparse_arch.embedding_bag_collection)
             if defer is not None:
                 defer(True)
