@@ -435,3 +435,66 @@ def _check_seq(ret, W, D=4):
             np.testing.assert_allclose(w, tabs.weights[int(name[1:])][row0:row0 + w.shape[0]], rtol=1e-5, atol=1e-5)
             seen[name] += w.shape[0]
     assert seen == {"t0": 30, "t1": 11, "t2": 19}
+
+
+def _half_exchange_worker(rank, W, port, n_rw, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=W)
+    try:
+        import _cpu_ops
+        _cpu_ops.register()
+        from _oracle_tbe import oracle_dp_tbe_factory, oracle_tbe_factory
+        from torchrec_amd.distributed._rehearsal import stage_all_to_all_through_host
+        from torchrec_amd.distributed.embeddingbag import ShardedEmbeddingBagCollection, _ExchangeState
+        from torchrec_amd.distributed.planner import EmbeddingShardingPlanner, Topology
+        from torchrec_amd.distributed.types import ShardingEnv
+        from torchrec_amd.modules.embedding_configs import EmbeddingBagConfig
+        from torchrec_amd.modules.embedding_modules import EmbeddingBagCollection
+
+        stage_all_to_all_through_host()  # gloo has no list-form all-to-all: one all_to_all_single underneath
+        keys = [f"f{i}" for i in range(len(ROWS))]
+        tables = [EmbeddingBagConfig(name=f"t{i}", embedding_dim=DIMS[i], num_embeddings=ROWS[i], feature_names=[keys[i]])
+                  for i in range(len(ROWS))]
+        ebc = EmbeddingBagCollection(tables, device=torch.device("meta"))
+        plan = EmbeddingShardingPlanner(Topology(W, "cpu"), num_row_wise=n_rw, dp_max_rows=0).plan_tables(tables)
+        sebc = ShardedEmbeddingBagCollection(ebc, plan, ShardingEnv.from_process_group(dist.group.WORLD), {"learning_rate": LR},
+                                             torch.device("cpu"), tbe_factory=oracle_tbe_factory,
+                                             dp_tbe_factory=oracle_dp_tbe_factory)
+        B = 6
+        g = torch.Generator().manual_seed(100 + rank)
+        emb = torch.randn(W * B, sebc._D_local, generator=g)  # what this rank's lookup would hand to the exchange
+        grad = torch.randn(B, sebc._D_total, generator=g)     # gradient of this rank's pooled output
+        whole = _ExchangeState(sebc, B)
+        whole.start_forward(emb)
+        out_whole = whole.finish_forward().clone()
+        whole.start_backward(grad)
+        back_whole = whole.finish_backward().clone()
+        halves = _ExchangeState(sebc, B)
+        halves.start_forward_halves(emb)
+        rows = [halves.finish_forward_half(h) for h in range(2)]
+        out_halves = halves.output_destination().clone()
+        assert rows[0].shape == (B // 2, sebc._D_total) and rows[1].data_ptr() == halves.output_destination()[B // 2:].data_ptr()
+        for h in range(2):
+            halves.start_backward_half(h, grad[h * (B // 2):(h + 1) * (B // 2)].contiguous())
+        back_halves = halves.finish_backward().clone()
+        ret[rank] = (out_whole.numpy(), out_halves.numpy(), back_whole.numpy(), back_halves.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_rw", [0, 2, 5])
+def test_half_batch_exchange_equals_whole_batch_world2(n_rw):
+    """The pooled exchange in two half-batches (_ExchangeState.start_forward_halves / finish_forward_half /
+    start_backward_half: list-form all-to-all over row-range views, unpack / pack with the B/2 layout on the half's rows)
+    moves exactly what the whole-batch exchange moves, forward and backward, table-wise and row-wise shards."""
+    from _results import ResultStore
+
+    W = 2
+    ret = ResultStore()
+    mp.spawn(_half_exchange_worker, args=(W, _free_port(), n_rw, ret), nprocs=W, join=True)
+    for r in range(W):
+        out_whole, out_halves, back_whole, back_halves = ret[r]
+        np.testing.assert_array_equal(out_halves, out_whole)
+        np.testing.assert_array_equal(back_halves, back_whole)
+        assert np.abs(out_whole).sum() > 0 and np.abs(back_whole).sum() > 0

@@ -42,9 +42,10 @@ def stage_all_to_all_through_host() -> None:
 
     def all_to_all(output_tensor_list, input_tensor_list, group=None, async_op=False):
         """The list form (pieces that are views, e.g. the half-batch exchange) through ONE host all_to_all_single."""
-        if not input_tensor_list or not input_tensor_list[0].is_cuda:
+        if not input_tensor_list:
             return real_list(output_tensor_list, input_tensor_list, group=group, async_op=async_op)
-        torch.cuda.current_stream(input_tensor_list[0].device).synchronize()
+        if input_tensor_list[0].is_cuda:  # (host tensors take the same route: gloo has no list-form all-to-all at all)
+            torch.cuda.current_stream(input_tensor_list[0].device).synchronize()
         dtype = input_tensor_list[0].dtype
         host_in = torch.cat([t.reshape(-1).cpu() for t in input_tensor_list])
         host_out = torch.empty(sum(t.numel() for t in output_tensor_list), dtype=dtype)
