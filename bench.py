@@ -553,6 +553,7 @@ def main(args):
             "dtype": "f32", "data": "synthetic", "hip_graphs": hip_graphs, "hip_graphs_note": graphs_note,
             "explicit_backward_steps": int(getattr(train_model, "explicit_steps", 0)),
             "half_batch_steps": int(getattr(train_model, "half_batch_steps", 0)),
+            "prefetched_lookups": int(getattr(train_model, "prefetched_lookups", 0)),
             "tuned_gemms": tuned,
             "rccl_ranks": dist.get_world_size() if dist.is_initialized() and dist.get_backend() == "nccl" else 0,
             "backend": dist.get_backend() if dist.is_initialized() else None,
@@ -562,7 +563,7 @@ def main(args):
             "env": {k: os.environ[k] for k in ("GPU_MAX_HW_QUEUES", "HSA_ENABLE_IPC_MODE_LEGACY", "TORCHREC_AMD_RW_INPUT_DIST",
                                                "TORCHREC_AMD_PREFETCH_LOOKUP", "TORCHREC_AMD_FUSED_BCE",
                                                "TORCHREC_AMD_REHEARSAL_LINK_US", "TORCHREC_AMD_RCCL_HIGH_PRIORITY",
-                                               "TBE_STREAM_PROBE", "TORCHREC_AMD_HALF_BATCHES") if k in os.environ},
+                                               "TBE_STREAM_PROBE", "TORCHREC_AMD_HALF_BATCHES", "TORCHREC_AMD_WGRAD_LATE_LAYERS") if k in os.environ},
             "config": {"workload": "DLRM Criteo-1TB shape: 26 tables (177.9M rows, 84.85 GiB fp32, D=128), 13 dense, "
                                    "pooling factor 1, dense 512-256-128, over 1024-1024-512-256-1, fused exact SGD",
                        "global_batch": args.global_batch, "local_batch": B_local,

@@ -125,3 +125,18 @@ def test_bench_rehearsal_with_the_exchange_in_two_half_batches():
         assert abs(whole["checks"][k] - halves["checks"][k]) <= 2e-4 * abs(whole["checks"][k]), (k, whole["checks"], halves["checks"])
     for k in ("dense", "embedding"):
         assert _close(whole["checks"]["param_checksum"][k], halves["checks"]["param_checksum"][k], 2e-6), k
+
+
+def test_late_weight_gradients_behind_the_prefetched_lookup_change_no_bit():
+    """Default explicit step (part of the head's weight gradients replayed behind the NEXT step's prefetched lookup +
+    all-to-all) against the same run with everything in its old place: a reordering of independent work, so losses and
+    parameter checksums must be IDENTICAL — in particular the prefetched step must not read the replicated tables before
+    the dense optimizer has updated them."""
+    env = {"TORCHREC_AMD_FORCE_EXCHANGE": "1", "TORCHREC_AMD_FORCE_DP": "1", "MASTER_PORT": "29564"}
+    plain = _run(dict(env, TORCHREC_AMD_WGRAD_LATE_LAYERS="0", TORCHREC_AMD_PREFETCH_LOOKUP="0"), "--global-batch", "4096")
+    late = _run(env, "--global-batch", "4096")
+    assert late["explicit_backward_steps"] == plain["explicit_backward_steps"] == 7
+    assert late["prefetched_lookups"] > 0 and plain["prefetched_lookups"] == 0
+    assert late["checks"]["loss_first"] == plain["checks"]["loss_first"]
+    assert late["checks"]["loss_last"] == plain["checks"]["loss_last"]
+    assert late["checks"]["param_checksum"] == plain["checks"]["param_checksum"]

@@ -1050,14 +1050,15 @@ class ShardedEmbeddingBagCollection(nn.Module):
                 and buf.numel() == batch_size * self._D_total and hasattr(self._emb_module, "lookup_no_autograd")
                 and (self._dp_module is None or hasattr(self._dp_module, "lookup_no_autograd")))
 
-    def compute_explicit(self, dist_input: SparseFeaturesDist) -> "ExplicitLookupStep":
+    def compute_explicit(self, dist_input: SparseFeaturesDist, prefetched: bool = False) -> "ExplicitLookupStep":
         """compute_and_output_dist for a caller that runs the backward ITSELF (no autograd nodes): lookup + start of the
         pooled all-to-all now, `finish()` = wait + unpack (+ replicated tables) into the output buffer,
         `start_backward(grad)` = pack + gradient all-to-all (+ the replicated tables' backward), `finish_backward()` =
-        the fused backward.  Check explicit_step_supported() first."""
+        the fused backward.  Check explicit_step_supported() first.  `prefetched`: the call is made at the END of the previous
+        step, before its dense optimizer — everything that reads dense parameters (the replicated tables) waits for finish()."""
         if not self.explicit_step_supported(dist_input.batch_size):
             raise RuntimeError("compute_explicit: not available for this configuration (explicit_step_supported())")
-        return ExplicitLookupStep(self, dist_input, halves=self.half_batch_exchange)
+        return ExplicitLookupStep(self, dist_input, halves=self.half_batch_exchange, early_replicated_lookup=not prefetched)
 
     def forward(self, features: KeyedJaggedTensor) -> Awaitable[KeyedTensor]:
         return self.compute_and_output_dist(self.input_dist(features).wait())
@@ -1068,7 +1069,8 @@ class ExplicitLookupStep:
     With the exchange: lookup in all-to-all layout -> pooled all-to-all -> unpack into the output buffer; without
     (one rank): the lookup writes its column blocks of the output buffer directly."""
 
-    def __init__(self, owner: "ShardedEmbeddingBagCollection", dist_input: SparseFeaturesDist, halves: bool = False) -> None:
+    def __init__(self, owner: "ShardedEmbeddingBagCollection", dist_input: SparseFeaturesDist, halves: bool = False,
+                 early_replicated_lookup: bool = True) -> None:
         self.o, self.d = owner, dist_input
         self.halves = bool(halves and owner._exchange)  # two half-batch exchanges (finish_half / start_backward_half)
         self.dp_rec = None
@@ -1095,7 +1097,9 @@ class ExplicitLookupStep:
                 self.state.start_forward(emb)
             # the replicated tables' lookup does not depend on the exchange: it fills its columns of the destination
             # while the all-to-all (on its own hardware queue) is in flight, instead of after the wait
-            self._early_dp = owner._dp_module is not None
+            # (NOT when this step is prefetched at the end of the previous one: the replicated tables are dense parameters,
+            # the previous step's dense optimizer has not run yet — finish() does the lookup then)
+            self._early_dp = owner._dp_module is not None and early_replicated_lookup
             if self._early_dp:
                 v, offs, w = dist_input.dp
                 with label("## tbe_lookup ##"):
@@ -1114,15 +1118,22 @@ class ExplicitLookupStep:
     def finish(self) -> torch.Tensor:
         """[B_local, sum D] pooled embeddings in the collection's key order, inside the output buffer."""
         o = self.o
-        out = self.state.finish_forward() if self.state is not None else self._out
-        if o._dp_module is not None and not self._early_dp:
+        self._late_dp_lookup()
+        return self.state.finish_forward() if self.state is not None else self._out
+
+    def _late_dp_lookup(self) -> None:
+        """The replicated tables' lookup of a step that could not do it early: ahead of the wait for the exchange."""
+        o = self.o
+        if o._dp_module is not None and not self._early_dp and self.dp_rec is None:
             v, offs, w = self.d.dp
-            out, self.dp_rec = o._dp_module.lookup_no_autograd(v, offs, w, into=(out, o._dp_out_off, o._D_total))
-        return out
+            dest = self.state.output_destination() if self.state is not None else self._out
+            with label("## tbe_lookup ##"):
+                _, self.dp_rec = o._dp_module.lookup_no_autograd(v, offs, w, into=(dest, o._dp_out_off, o._D_total))
 
     def finish_half(self, h: int) -> torch.Tensor:
         """Half-batch mode: rows [h B/2, (h + 1) B/2) of the pooled output, complete (the replicated tables' columns were
         filled for the whole batch while the exchange was in flight)."""
+        self._late_dp_lookup()
         return self.state.finish_forward_half(h)
 
     def start_backward_half(self, h: int, grad_rows: torch.Tensor, grad_out: Optional[torch.Tensor] = None) -> None:

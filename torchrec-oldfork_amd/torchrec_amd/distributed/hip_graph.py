@@ -49,6 +49,8 @@ class _Replay(torch.autograd.Function):
         seg.bwd_graph.replay()
         if getattr(seg, "bwd_graph2", None) is not None:
             seg.bwd_graph2.replay()  # deferred weight gradients (capture_backward(defer_wgrad=True))
+        if getattr(seg, "bwd_graph3", None) is not None:
+            seg.bwd_graph3.replay()  # ... the late part of them (late_params)
         if seg.param_grad_sinks is not None:
             # parameter gradients were written (scaled) into the caller's flat buffer inside the graph;
             # autograd gets none, the owner of the buffer is told they are ready
@@ -111,7 +113,7 @@ class GraphedSegment(nn.Module):
 
     def capture_backward(self, grad_output_buffers: Optional[Sequence[Optional[torch.Tensor]]] = None,
                          param_grad_sinks: Optional[Sequence[torch.Tensor]] = None, sink_scale: float = 1.0,
-                         defer_wgrad: bool = False) -> None:
+                         defer_wgrad: bool = False, late_params: int = 0) -> None:
         """Captures d(outputs)/d(inputs, parameters).  `grad_output_buffers[i]` lets a downstream
         segment's static input-gradient buffer double as this segment's output-gradient buffer.
         `param_grad_sinks[j]` (one per parameter, in `parameters()` order): the graph itself writes
@@ -120,7 +122,11 @@ class GraphedSegment(nn.Module):
         `defer_wgrad`: the weight-gradient GEMMs of the segment's Linear layers (modules/mlp.py) and the writes into the
         sinks go into a SECOND graph, `bwd_graph2`; `bwd_graph` then ends with the input gradients, and an owner that
         drives the step itself can start what depends on them (the embedding-gradient all-to-all) before it replays the
-        second graph.  `_Replay.backward` replays both back to back."""
+        second graph.  `_Replay.backward` replays both back to back.
+        `late_params` (with defer_wgrad and sinks): the gradients of the FIRST `late_params` parameters (in `parameters()`
+        order: the first layers of an MLP) go into a THIRD graph, `bwd_graph3`, the rest stay in `bwd_graph2` — an owner
+        can then put one part behind the gradient all-to-all and the other behind the NEXT step's prefetched forward
+        all-to-all (models/dlrm.py).  `_Replay.backward` replays all three back to back."""
         from ..modules.mlp import _DeferredWgrad
 
         outs = self.static_outputs
@@ -134,11 +140,14 @@ class GraphedSegment(nn.Module):
         if param_grad_sinks is not None and len(param_grad_sinks) != len(self._params):
             raise ValueError("one gradient sink per parameter")
 
-        def write_sinks(pg_, partials=None) -> None:
+        def write_sinks(pg_, partials=None, lo: int = 0, hi: Optional[int] = None) -> None:
             """pg_[j]: complete gradient of parameter j or None; partials[j] (optional): [chunks, *shape] whose sum over
-            dim 0 is the gradient (split-K slices, row-block sums: modules/mlp.py _DeferredWgrad)."""
-            sinks = list(param_grad_sinks)
-            partials = partials if partials is not None else [None] * len(sinks)
+            dim 0 is the gradient (split-K slices, row-block sums: modules/mlp.py _DeferredWgrad).  [lo, hi): the
+            parameters this call finishes."""
+            hi = len(param_grad_sinks) if hi is None else hi
+            sinks = list(param_grad_sinks)[lo:hi]
+            pg_ = list(pg_)[lo:hi]
+            partials = list(partials)[lo:hi] if partials is not None else [None] * len(sinks)
             consecutive = all(s_.is_contiguous() for s_ in sinks) and all(
                 sinks[i + 1].data_ptr() == sinks[i].data_ptr() + sinks[i].numel() * sinks[i].element_size()
                 for i in range(len(sinks) - 1))
@@ -174,7 +183,7 @@ class GraphedSegment(nn.Module):
                 # overwritten by that graph's every replay (a table placed in the pool produced exactly that: a wild source
                 # pointer and a memory aperture violation in the first replayed step).  Its contents — addresses that are
                 # final only now — are uploaded ONCE, right after the capture has ended (below).
-                table = sink_table
+                table = sink_tables.pop()[:len(rows)]
                 torch.ops.tbe_hip.multi_chunk_sum(table, len(rows), max(r[2] for r in rows), flat_slice, float(sink_scale))
                 self._sink_tables.append((table, rows, keep))
             else:
@@ -185,13 +194,18 @@ class GraphedSegment(nn.Module):
                         sink.zero_()
                     else:
                         torch.mul(g, sink_scale, out=sink)
-            self.param_grad_sinks = sinks
+            self.param_grad_sinks = list(param_grad_sinks)
 
         self.bwd_graph = torch.cuda.CUDAGraph()
         self.bwd_graph2: Optional[torch.cuda.CUDAGraph] = None
+        self.bwd_graph3: Optional[torch.cuda.CUDAGraph] = None
         self._sink_tables = []  # (device segment table, its rows, the source tensors kept alive)
-        sink_table = (torch.zeros((len(param_grad_sinks), 4), dtype=torch.int64, device=param_grad_sinks[0].device)
-                      if param_grad_sinks else None)  # ordinary allocation: NOT in the graphs' pool (see write_sinks)
+        # ordinary allocations: NOT in the graphs' pool (see write_sinks); one per write_sinks call
+        sink_tables = ([torch.zeros((len(param_grad_sinks), 4), dtype=torch.int64, device=param_grad_sinks[0].device)
+                        for _ in range(2)] if param_grad_sinks else [])
+        late_params = int(late_params) if (defer_wgrad and param_grad_sinks is not None) else 0
+        if not 0 <= late_params <= len(self._params):
+            raise ValueError("late_params out of range")
         if defer_wgrad and self.static_inputs[0].is_cuda:
             # the deferred weight gradients run batched GEMMs (modules/mlp.py compute_partials) that the warm-up never
             # ran: the BLAS handle of this stream must exist before the capture (creating it inside one fails with
@@ -217,32 +231,42 @@ class GraphedSegment(nn.Module):
                 write_sinks(grads[n_in:])
         if stash:
             index = {id(p): n_in + j for j, p in enumerate(self._params)}
-            partials = [None] * len(grads)
+
+            def finish(graph, lo: int, hi: int) -> None:
+                """Captures the stashed weight / bias gradients of parameters [lo, hi) and their write into the sinks."""
+                partials = [None] * len(grads)
+                with torch.cuda.graph(graph, pool=self._pool, stream=self._stream, capture_error_mode="thread_local"), \
+                        torch.no_grad():  # X of a layer is an activation inside the forward's autograd graph
+                    for entry in stash:
+                        kind, prm = entry[0], entry[1]
+                        k = index[id(prm)]
+                        if not n_in + lo <= k < n_in + hi:
+                            continue
+                        if kind == "w":
+                            _, _, gy, x, c = entry
+                            part = _DeferredWgrad.compute_partials(gy, x, c) if with_partials else None
+                            gw = None if with_partials else _DeferredWgrad.compute(gy, x, c)
+                        else:
+                            part, gw = entry[2], None
+                        if part is not None:
+                            part = part.reshape(part.shape[0], -1)
+                            partials[k] = part if partials[k] is None else torch.cat([partials[k], part])
+                        else:
+                            grads[k] = gw if grads[k] is None else grads[k] + gw
+                    if param_grad_sinks is not None:
+                        write_sinks(grads[n_in:], partials[n_in:], lo, hi)
+                    else:
+                        for k, part in enumerate(partials):
+                            if part is not None:  # not reached today (partials are only stashed with sinks); kept consistent
+                                full = part.sum(dim=0).view_as(self._params[k - n_in])
+                                grads[k] = full if grads[k] is None else grads[k] + full
+
             self.bwd_graph2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.bwd_graph2, pool=self._pool, stream=self._stream, capture_error_mode="thread_local"), \
-                    torch.no_grad():  # X of a layer is an activation inside the forward's autograd graph
-                for entry in stash:
-                    kind, prm = entry[0], entry[1]
-                    k = index[id(prm)]
-                    if kind == "w":
-                        _, _, gy, x, c = entry
-                        part = _DeferredWgrad.compute_partials(gy, x, c) if with_partials else None
-                        gw = None if with_partials else _DeferredWgrad.compute(gy, x, c)
-                    else:
-                        part, gw = entry[2], None
-                    if part is not None:
-                        part = part.reshape(part.shape[0], -1)
-                        partials[k] = part if partials[k] is None else torch.cat([partials[k], part])
-                    else:
-                        grads[k] = gw if grads[k] is None else grads[k] + gw
-                if param_grad_sinks is not None:
-                    write_sinks(grads[n_in:], partials[n_in:])
-                else:
-                    for k, part in enumerate(partials):
-                        if part is not None:  # not reached today (partials are only stashed with sinks); kept consistent
-                            full = part.sum(dim=0).view_as(self._params[k - n_in])
-                            grads[k] = full if grads[k] is None else grads[k] + full
-            self._wgrad_stash = stash  # dY / X of the first graph stay allocated: the second graph reads them
+            finish(self.bwd_graph2, late_params, len(self._params))
+            if late_params:
+                self.bwd_graph3 = torch.cuda.CUDAGraph()
+                finish(self.bwd_graph3, 0, late_params)
+            self._wgrad_stash = stash  # dY / X of the first graph stay allocated: the later graphs read them
         for table, rows, _ in self._sink_tables:  # outside every capture: fill the segment tables the graphs read
             table.copy_(torch.tensor(rows, dtype=torch.int64))
         if self._sink_tables:

@@ -42,12 +42,12 @@ class _PipelinedEBC(torch.nn.Module):
     def forward(self, features):
         return self.sharded.compute_and_output_dist(self._dist_input(features))
 
-    def compute_explicit(self, features):
+    def compute_explicit(self, features, prefetched: bool = False):
         """The no-autograd step of the wrapped collection (embeddingbag.py ExplicitLookupStep) on this batch's queued
         input dist, or None when the collection cannot run it (nothing is consumed then)."""
         if not hasattr(self.sharded, "compute_explicit") or not self.sharded.explicit_step_supported(features.stride()):
             return None
-        return self.sharded.compute_explicit(self._dist_input(features))
+        return self.sharded.compute_explicit(self._dist_input(features), prefetched=prefetched)
 
 
 class TrainPipelineSparseDist:
@@ -76,14 +76,13 @@ class TrainPipelineSparseDist:
         self._data_dist_stream = side_stream(device) if use_streams else None
         self._requests = {}
         # explicit-step models: enqueue batch i+1's lookup + pooled all-to-all right behind batch i's embedding backward
-        # (prefetch_lookup=True or TORCHREC_AMD_PREFETCH_LOOKUP=1).  Opt-in: in the one-rank rehearsal at the 8-GPU per-rank
-        # batch it measures 0.5 % SLOWER (1.879 vs 1.871 ms, 1.841 vs 1.832 on another box: the host runs ~70 steps ahead
-        # of the GPU there, so nothing waits for the host at the step boundary, and the all-to-all then overlaps the dense
-        # SGD instead of the bottom MLP); what it can buy on real links — the lookup hidden behind the dense gradient
-        # all-reduce — cannot be measured on a one-GPU box
+        # (prefetch_lookup=True / False, or TORCHREC_AMD_PREFETCH_LOOKUP=1 / 0).  Unset: on when the model kept part of its
+        # weight gradients for exactly that window (DLRMTrain.wants_lookup_prefetch: the late weight-gradient graph then
+        # runs while the prefetched all-to-all is on the links), off otherwise — on its own the prefetch measured 0.5 %
+        # SLOWER in the one-rank rehearsal (nothing but the dense SGD is left to overlap: DESIGN.md §3c)
         import os
-        self._prefetch = (os.environ.get("TORCHREC_AMD_PREFETCH_LOOKUP", "0") == "1") if prefetch_lookup is None \
-            else bool(prefetch_lookup)
+        env = os.environ.get("TORCHREC_AMD_PREFETCH_LOOKUP")
+        self._prefetch = bool(prefetch_lookup) if prefetch_lookup is not None else (env == "1" if env is not None else None)
         self._batch_i = None
         self._batch_ip1 = None
         self._batch_ip2 = None
@@ -141,7 +140,7 @@ class TrainPipelineSparseDist:
         if emb is None or getattr(emb, "_cache", None) is not None:
             return None  # a row cache allows one outstanding training forward; keep those strictly in order
         with label("## prefetch_next_lookup ##"):
-            step = w.compute_explicit(nxt.sparse_features)
+            step = w.compute_explicit(nxt.sparse_features, prefetched=True)
         return (nxt.sparse_features, step) if step is not None else None
 
     def _run_backward(self, losses) -> None:
@@ -249,7 +248,8 @@ class TrainPipelineSparseDist:
         if explicit:
             # a model that runs its own backward inside forward (models/dlrm.py explicit step) calls this between the two
             # (and labels its own "## forward ##" / "## backward ##" ranges then)
-            root.set_between_forward_and_backward(start_next_input_dist, self._prefetch_next_lookup if self._prefetch else None)
+            prefetch = self._prefetch if self._prefetch is not None else bool(getattr(root, "wants_lookup_prefetch", False))
+            root.set_between_forward_and_backward(start_next_input_dist, self._prefetch_next_lookup if prefetch else None)
         with label("## forward ##"):  # train_pipeline.py:520 (an explicit step nests "## backward ##" inside)
             losses, output = self._model(batch)
         start_next_input_dist()

@@ -63,6 +63,11 @@ _DEFER_WGRAD = os.environ.get("TORCHREC_AMD_DEFER_WGRAD", "1") != "0"
 # link times: 7.01 -> 6.30 ms per step at 32 768 per rank; a tie at 16 384 (3.40 / 3.38) and a loss at 8192
 # (1.86 -> 2.01): two half-size passes cost 0.2 - 0.3 ms more kernel time (GEMMs at half M, kernels at their latency floor).
 # "1" / "0" force it.
+# Flat-gradient graph mode under a pipeline that prefetches the next lookup: the weight / bias gradients of the head's FIRST
+# this-many Linear layers are captured into a third graph that the explicit step replays AFTER it has started the NEXT step's
+# lookup + pooled all-to-all (the rest stays behind this step's gradient all-to-all).  The forward all-to-all then has the
+# same kind of cover the gradient all-to-all always had, instead of the bottom MLP's forward only.  0 = off.
+_WGRAD_LATE_LAYERS = int(os.environ.get("TORCHREC_AMD_WGRAD_LATE_LAYERS", "2"))
 _HALF_BATCHES = os.environ.get("TORCHREC_AMD_HALF_BATCHES", "auto")
 _HALF_BATCH_MIN = int(os.environ.get("TORCHREC_AMD_HALF_BATCH_MIN", "32768"))
 
@@ -374,6 +379,13 @@ class DLRMTrain(nn.Module):
 
             world = dist.get_world_size(process_group) if process_group is not None else 1
             scale = 1.0 / world
+            dense_pg = process_group
+            if world > 1 and dist.get_backend(process_group) == "nccl" and os.environ.get("TORCHREC_AMD_DENSE_PG", "1") == "1":
+                # the dense all-reduces get a communicator (and stream) of their own: on the collection's they would queue
+                # behind a pooled all-to-all that is waiting for its links (the prefetched one, above all)
+                from ..distributed.comm import rccl_options
+
+                dense_pg = dist.new_group(ranks=dist.get_process_group_ranks(process_group), pg_options=rccl_options())
             graphed = {id(q) for q in list(g_head._params) + list(g_dense._params)}
             # every other trainable dense parameter of the model (the replicated tiny tables of a sharded
             # collection): its gradient arrives through autograd and joins the flat buffer after backward
@@ -395,12 +407,18 @@ class DLRMTrain(nn.Module):
             extra_views = views(extras, n_head + n_dense)
             state = {"flat": flat, "flat_param": flat_param, "params": list(g_head._params) + list(g_dense._params) + extras,
                      "views": head_sinks + dense_sinks + extra_views, "extras": list(zip(extras, extra_views)),
-                     "n_head": n_head, "works": [], "pg": process_group, "world": world, "scale": scale}
+                     "n_head": n_head, "works": [], "pg": dense_pg, "world": world, "scale": scale}
 
             def reduce_head():  # the head's backward runs first: its slice overlaps the rest of backward
                 state["fired"] += 1
-                if state["world"] > 1:
-                    state["works"].append(dist.all_reduce(flat[:n_head], group=state["pg"], async_op=True))
+                if state["world"] > 1:  # (without the late part: its gradients do not exist yet, reduce_late() follows)
+                    state["works"].append(dist.all_reduce(flat[state.get("n_late", 0):n_head], group=state["pg"], async_op=True))
+
+            def reduce_late():
+                if state["world"] > 1 and state.get("n_late", 0):
+                    state["works"].append(dist.all_reduce(flat[:state["n_late"]], group=state["pg"], async_op=True))
+
+            state["reduce_late"] = reduce_late
 
             def dense_done():
                 state["fired"] += 1
@@ -439,7 +457,17 @@ class DLRMTrain(nn.Module):
                 ebc.set_output_buffer(g_head.static_input(1).detach())
             # flat mode: the head's weight gradients go into a second graph that the explicit step replays after it has
             # started the embedding-gradient all-to-all (modules/mlp.py _DeferredWgrad)
-            g_head.capture_backward(param_grad_sinks=head_sinks, sink_scale=scale, defer_wgrad=flat_grads and _DEFER_WGRAD)
+            late = 0
+            if flat_grads and _DEFER_WGRAD and _EXPLICIT_STEP and getattr(ebc, "_exchange", False):
+                # (weight, bias) of the over arch's first layers: the leading parameters of the head segment
+                n_lin = sum(1 for q in g_head._params if q.dim() == 2)
+                late = 2 * min(_WGRAD_LATE_LAYERS, max(n_lin - 1, 0))
+                if late and not all(g_head._params[j].dim() == (2 if j % 2 == 0 else 1) for j in range(late)):
+                    late = 0  # not a plain (weight, bias) sequence: keep everything in the second graph
+            g_head.capture_backward(param_grad_sinks=head_sinks, sink_scale=scale, defer_wgrad=flat_grads and _DEFER_WGRAD,
+                                    late_params=late)
+            if flat_grads:
+                state["n_late"] = sum(q.numel() for q in g_head._params[:late]) if g_head.bwd_graph3 is not None else 0
             # the head's gradient w.r.t. the bottom-MLP output doubles as the bottom segment's grad_output buffer
             g_dense.capture_backward([g_head.static_grad_inputs[0]], param_grad_sinks=dense_sinks, sink_scale=scale,
                                      defer_wgrad=flat_grads and _DEFER_WGRAD)
@@ -542,6 +570,13 @@ class DLRMTrain(nn.Module):
         object.__setattr__(self, "_between", fn)
         object.__setattr__(self, "_prefetch", prefetch)
 
+    @property
+    def wants_lookup_prefetch(self) -> bool:
+        """True when the captured head segment keeps part of its weight gradients for the window behind the next step's
+        prefetched lookup (capture_hip_graphs, TORCHREC_AMD_WGRAD_LATE_LAYERS): the pipeline then prefetches by default."""
+        g = getattr(self, "_graphs", None)
+        return bool(g is not None and getattr(self, "_half", None) is None and getattr(g[2], "bwd_graph3", None) is not None)
+
     def take_backward_done(self) -> bool:
         """True (once) when the latest forward() already ran the backward: the caller must not call loss.backward()."""
         done = getattr(self, "_backward_done", False)
@@ -565,6 +600,7 @@ class DLRMTrain(nn.Module):
         object.__setattr__(self, "_prefetched", None)
         if pre is not None and pre[0] is kjt:
             step = pre[1]  # looked up (and its all-to-all started) at the end of the previous step
+            object.__setattr__(self, "prefetched_lookups", getattr(self, "prefetched_lookups", 0) + 1)
         else:
             if pre is not None:
                 raise RuntimeError("DLRMTrain: a lookup was prefetched for another batch than the one this step received; the "
@@ -618,6 +654,12 @@ class DLRMTrain(nn.Module):
             prefetch = getattr(self, "_prefetch", None)
             if prefetch is not None:
                 object.__setattr__(self, "_prefetched", prefetch())  # (kjt, ExplicitLookupStep) of the NEXT batch, or None
+            if getattr(g_head, "bwd_graph3", None) is not None:
+                # the late part of the head's weight gradients: behind the NEXT step's lookup + pooled all-to-all when the
+                # owner prefetches (its cover on the links), right here otherwise
+                g_head.bwd_graph3.replay()
+                if st is not None:
+                    st["reduce_late"]()
         object.__setattr__(self, "_backward_done", True)
         object.__setattr__(self, "explicit_steps", getattr(self, "explicit_steps", 0) + 1)  # for tests / bench.py's line
         return loss.detach(), (loss.detach(), logits.detach(), batch.labels.detach())
