@@ -427,6 +427,13 @@ class DLRMTrain(nn.Module):
             g_head.after_backward = reduce_head
             g_dense.after_backward = dense_done
             object.__setattr__(self, "_flat_dense", state)
+        late = 0
+        if flat_grads and _DEFER_WGRAD and _EXPLICIT_STEP and getattr(ebc, "_exchange", False):
+            # (weight, bias) of the over arch's first layers: the leading parameters of the head segment
+            n_lin = sum(1 for q in g_head._params if q.dim() == 2)
+            late = 2 * min(_WGRAD_LATE_LAYERS, max(n_lin - 1, 0))
+            if late and not all(g_head._params[j].dim() == (2 if j % 2 == 0 else 1) for j in range(late)):
+                late = 0  # not a plain (weight, bias) sequence: keep everything in the second graph
         # the embedding collection writes its pooled output straight into the head segment's static input
         if hasattr(ebc, "set_half_batch_exchange"):
             ebc.set_half_batch_exchange(halves)
@@ -442,7 +449,7 @@ class DLRMTrain(nn.Module):
             half["tmp"], half["n_head_used"] = tmp, off
             for h, gh in enumerate(heads):
                 gh.capture_backward(param_grad_sinks=tmp_sinks if h == 0 else head_sinks, sink_scale=scale,
-                                    defer_wgrad=_DEFER_WGRAD)
+                                    defer_wgrad=_DEFER_WGRAD, late_params=late)
                 rows = slice(h * Bh, (h + 1) * Bh)
                 if (gh.static_grad_inputs[0].data_ptr() != half["gd"][rows].data_ptr()
                         or gh.static_grad_inputs[1].data_ptr() != half["gs"][rows].data_ptr()):
@@ -450,6 +457,7 @@ class DLRMTrain(nn.Module):
                                        "in the shared whole-batch buffers (is the fused dot interaction in use?)")
             heads[1].after_backward = heads[0].after_backward = None
             half["heads"], half["reduce_head"] = heads, reduce_head
+            state["n_late"] = sum(q.numel() for q in g_head._params[:late]) if heads[1].bwd_graph3 is not None else 0
             g_dense.capture_backward([half["gd"]], param_grad_sinks=dense_sinks, sink_scale=scale, defer_wgrad=_DEFER_WGRAD)
             object.__setattr__(self, "_half", half)
         else:
@@ -457,13 +465,6 @@ class DLRMTrain(nn.Module):
                 ebc.set_output_buffer(g_head.static_input(1).detach())
             # flat mode: the head's weight gradients go into a second graph that the explicit step replays after it has
             # started the embedding-gradient all-to-all (modules/mlp.py _DeferredWgrad)
-            late = 0
-            if flat_grads and _DEFER_WGRAD and _EXPLICIT_STEP and getattr(ebc, "_exchange", False):
-                # (weight, bias) of the over arch's first layers: the leading parameters of the head segment
-                n_lin = sum(1 for q in g_head._params if q.dim() == 2)
-                late = 2 * min(_WGRAD_LATE_LAYERS, max(n_lin - 1, 0))
-                if late and not all(g_head._params[j].dim() == (2 if j % 2 == 0 else 1) for j in range(late)):
-                    late = 0  # not a plain (weight, bias) sequence: keep everything in the second graph
             g_head.capture_backward(param_grad_sinks=head_sinks, sink_scale=scale, defer_wgrad=flat_grads and _DEFER_WGRAD,
                                     late_params=late)
             if flat_grads:
@@ -575,7 +576,7 @@ class DLRMTrain(nn.Module):
         """True when the captured head segment keeps part of its weight gradients for the window behind the next step's
         prefetched lookup (capture_hip_graphs, TORCHREC_AMD_WGRAD_LATE_LAYERS): the pipeline then prefetches by default."""
         g = getattr(self, "_graphs", None)
-        return bool(g is not None and getattr(self, "_half", None) is None and getattr(g[2], "bwd_graph3", None) is not None)
+        return bool(g is not None and getattr(g[2], "bwd_graph3", None) is not None)
 
     def take_backward_done(self) -> bool:
         """True (once) when the latest forward() already ran the backward: the caller must not call loss.backward()."""
@@ -694,10 +695,10 @@ class DLRMTrain(nn.Module):
                 for gh in heads:
                     if getattr(gh, "bwd_graph2", None) is not None:
                         gh.bwd_graph2.replay()  # weight gradients, while the gradient all-to-alls are in flight
-                n = half["n_head_used"]
+                n, nl = half["n_head_used"], self._flat_dense.get("n_late", 0)
                 st = self._flat_dense
-                st["flat"][:n].add_(half["tmp"][:n])
-                half["reduce_head"]()  # all-reduce of the head's slice of the flat gradient
+                st["flat"][nl:n].add_(half["tmp"][nl:n])
+                half["reduce_head"]()  # all-reduce of the head's slice of the flat gradient (without the late part)
                 g_dense.bwd_graph.replay()
                 if getattr(g_dense, "bwd_graph2", None) is not None:
                     g_dense.bwd_graph2.replay()
@@ -706,6 +707,14 @@ class DLRMTrain(nn.Module):
                 if st["fired"] == 2:
                     self._start_rest_reduce(st)
                 step.finish_backward()
+            prefetch = getattr(self, "_prefetch", None)
+            if prefetch is not None:
+                object.__setattr__(self, "_prefetched", prefetch())  # (kjt, ExplicitLookupStep) of the NEXT batch, or None
+            if nl:
+                for gh in heads:
+                    gh.bwd_graph3.replay()  # late weight gradients: behind the next step's first half-batch all-to-all
+                st["flat"][:nl].add_(half["tmp"][:nl])
+                st["reduce_late"]()
             loss = (heads[0].static_outputs[0] + heads[1].static_outputs[0]) * 0.5
             logits = torch.cat([heads[0].static_outputs[1], heads[1].static_outputs[1]])
         object.__setattr__(self, "_backward_done", True)
