@@ -1153,7 +1153,7 @@ class DenseTableBatchedEmbeddingBagsCodegen(_TBEBase):
         # ~90 K ids of the replicated tiny tables) starts now on the module's side stream, as the fused module's does
         mode = self.overlap_backward_sort
         if mode in (True, "1") or (mode == "auto" and indices.numel() <= self.overlap_backward_sort_max_ids_explicit):
-            rec.prepared = self._prepare_backward(indices, offsets, B, per_sample_weights is not None)
+            rec.prepared = self._prepare_or_defer(rec, indices, offsets, B, per_sample_weights is not None)
         return out, rec
 
     def backward_no_autograd(self, rec: "LookupRecord", grad_out: torch.Tensor) -> torch.Tensor:

@@ -1077,6 +1077,7 @@ class ExplicitLookupStep:
         self.state: Optional[_ExchangeState] = None
         self._grad: Optional[torch.Tensor] = None
         self._early_dp = False
+        self._dp_sort_pending = False
         if owner._exchange:
             # order of the HOST calls: lookup kernel, pooled all-to-all, THEN the backward's side-stream sort (6 launches,
             # ~60 us of host time): the all-to-all is on the step's critical path, the sort is not
@@ -1117,9 +1118,10 @@ class ExplicitLookupStep:
 
     def finish(self) -> torch.Tensor:
         """[B_local, sum D] pooled embeddings in the collection's key order, inside the output buffer."""
-        o = self.o
         self._late_dp_lookup()
-        return self.state.finish_forward() if self.state is not None else self._out
+        out = self.state.finish_forward() if self.state is not None else self._out
+        self._launch_late_dp_sort()
+        return out
 
     def _late_dp_lookup(self) -> None:
         """The replicated tables' lookup of a step that could not do it early: ahead of the wait for the exchange."""
@@ -1127,14 +1129,32 @@ class ExplicitLookupStep:
         if o._dp_module is not None and not self._early_dp and self.dp_rec is None:
             v, offs, w = self.d.dp
             dest = self.state.output_destination() if self.state is not None else self._out
-            with label("## tbe_lookup ##"):
-                _, self.dp_rec = o._dp_module.lookup_no_autograd(v, offs, w, into=(dest, o._dp_out_off, o._D_total))
+            # its backward's side-stream sort (5 launches of host time) goes behind the unpack launch: the host is what the
+            # GPU waits for at this point of the step
+            m = o._dp_module
+            can_defer = hasattr(m, "launch_deferred_backward_sort") and not getattr(m, "defer_backward_sort", False)
+            if can_defer:
+                m.defer_backward_sort = True
+            try:
+                with label("## tbe_lookup ##"):
+                    _, self.dp_rec = m.lookup_no_autograd(v, offs, w, into=(dest, o._dp_out_off, o._D_total))
+            finally:
+                if can_defer:
+                    m.defer_backward_sort = False
+            self._dp_sort_pending = can_defer
+
+    def _launch_late_dp_sort(self) -> None:
+        if self._dp_sort_pending:
+            self._dp_sort_pending = False
+            self.o._dp_module.launch_deferred_backward_sort()
 
     def finish_half(self, h: int) -> torch.Tensor:
         """Half-batch mode: rows [h B/2, (h + 1) B/2) of the pooled output, complete (the replicated tables' columns were
         filled for the whole batch while the exchange was in flight)."""
         self._late_dp_lookup()
-        return self.state.finish_forward_half(h)
+        rows = self.state.finish_forward_half(h)
+        self._launch_late_dp_sort()
+        return rows
 
     def start_backward_half(self, h: int, grad_rows: torch.Tensor, grad_out: Optional[torch.Tensor] = None) -> None:
         """Half-batch mode: packs and starts the gradient all-to-all of half h.  With the LAST half pass `grad_out`, the
