@@ -578,3 +578,63 @@ def test_sharded_sequence_embedding_world2_on_one_gpu(row_wise):
     ret = ResultStore()
     mp.spawn(_seq_gpu_worker, args=(W, _free_port(), ret, row_wise), nprocs=W, join=True)
     _check_seq(ret, W)
+
+
+# ---- a prefetched lookup must not survive a load_state_dict between two steps ---------------------------------------
+
+def _reload_worker(rank, port, prefetch, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    from torchrec_amd.distributed.comm import init_rccl_process_group
+
+    init_rccl_process_group(dev, rank=0, world_size=1)
+    try:
+        import torchrec_amd.distributed.embeddingbag as eb
+        from torchrec_amd.datasets.random import Batch
+        from torchrec_amd.distributed.train_pipeline import TrainPipelineSparseDist
+        from torchrec_amd.distributed.types import ShardingEnv
+        from torchrec_amd.sparse.jagged_tensor import KeyedJaggedTensor
+
+        eb.FORCE_EXCHANGE = True
+        keys, model, opt = _e2e_model(ShardingEnv.from_process_group(dist.group.WORLD), dev, dp_max_rows=10,
+                                      graph_batch=E_B, flat=True)
+        _e2e_init_tables(model)
+        def plain(sd):  # sharded tables arrive as ShardedTensors over the local shard: take the shard
+            return {k: (v.local_shards()[0].tensor if hasattr(v, "local_shards") else v).detach().clone()
+                    for k, v in sd.items() if torch.is_tensor(v) or hasattr(v, "local_shards")}
+
+        start = plain(model.state_dict())
+        bl = [Batch(torch.from_numpy(d[:E_B]).to(dev),
+                    KeyedJaggedTensor.from_fixed_lengths(keys, torch.from_numpy(np.ascontiguousarray(i[:, :E_B]).reshape(-1)).to(dev),
+                                                         [1] * len(keys)),
+                    torch.from_numpy(lab[:E_B]).to(dev)) for d, i, lab in _e2e_batches(1)]
+        pipe = TrainPipelineSparseDist(model, opt, dev, hip_graphs=True, prefetch_lookup=prefetch)
+        model.train()
+        it = iter(bl)
+        losses = [float(pipe.progress(it)[0].detach()) for _ in range(2)]
+        model.load_state_dict(start)  # back to the initial model: the next step must see THESE tables
+        losses += [float(pipe.progress(it)[0].detach()) for _ in range(2)]
+        torch.cuda.synchronize()
+        ret[0] = (losses, int(getattr(model.module, "prefetched_lookups", 0)),
+                  {k: v.cpu().numpy() for k, v in plain(model.state_dict()).items()})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_load_state_dict_between_steps_discards_the_prefetched_lookup():
+    """The default explicit step prefetches the next batch's lookup at the end of a step.  A load_state_dict before the
+    next step rewrites the tables that lookup read: it must be redone (ExplicitLookupStep.epoch), so that the run equals
+    one without prefetch bit for bit."""
+    out = []
+    for prefetch in (False, True):
+        ret = ResultStore()
+        mp.spawn(_reload_worker, args=(_free_port(), prefetch, ret), nprocs=1, join=True)
+        out.append(ret[0])
+    (l0, n0, s0), (l1, n1, s1) = out
+    assert n0 == 0 and n1 >= 2  # steps 2 and 4 used their prefetched lookups, step 3's was discarded
+    assert l0 == l1
+    for k in s0:
+        np.testing.assert_array_equal(s0[k], s1[k], err_msg=k)

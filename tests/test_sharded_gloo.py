@@ -297,6 +297,7 @@ def _e2e_worker(rank, W, port, ret):
         opt = CombinedOptimizer([model.fused_optimizer,
                                  KeyedOptimizerWrapper(dict(model.named_parameters()), lambda p: torch.optim.SGD(p, lr=0.05))])
         data = RandomRecDataset(keys, 4, rows, manual_seed=100 + rank, num_generated_batches=3, num_batches=5, device=dev)
+        keys_before = (sorted(model.state_dict().keys()), sorted(k for k, _ in model.named_parameters()))
         pipe = TrainPipelineSparseDist(model, opt, dev)
         model.train()
         it = iter(data)
@@ -304,6 +305,10 @@ def _e2e_worker(rank, W, port, ret):
         for _ in range(3):
             loss = pipe.progress(it)[0]
             losses.append(float(loss))
+        # the pipeline rewrites the sharded module's forward on the instance (train_pipeline.py:193-243): the module tree,
+        # the parameter names and the state_dict keys are what they were, and a checkpoint taken before loads after
+        assert (sorted(model.state_dict().keys()), sorted(k for k, _ in model.named_parameters())) == keys_before
+        model.load_state_dict({k: (v.clone() if torch.is_tensor(v) else v) for k, v in model.state_dict().items()})
         # the 4th step under a torch profiler: the reference's range labels must show up (and only then: without a
         # profiler `label()` hands out a shared no-op context, torchrec_amd/profiling.py)
         from torchrec_amd import profiling

@@ -511,6 +511,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
         self._kjt_cache: Dict[Tuple, Any] = {}
         self._output_buffer: Optional[torch.Tensor] = None  # see set_output_buffer
         self.half_batch_exchange = False  # see set_half_batch_exchange
+        self._weights_epoch = 0  # bumped by everything that rewrites tables outside a train step (see ExplicitLookupStep.epoch)
         # ---- local tables + TBE ----------------------------------------------------------------
         self._local_tables: List[_LocalTable] = []
         local_table_index: Dict[int, int] = {}
@@ -620,6 +621,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
         unsharded one — then starts from the same tables, which is what lets a world-size-N run be compared with a
         world-size-1 run (the reference's tests copy a global model's state_dict into the shards instead:
         test_model_parallel_base.py:92-122)."""
+        self._weights_epoch += 1
         gen = torch.Generator(device=self._device)
         index = {c.name: t for t, c in enumerate(self._embedding_bag_configs)}
         targets = [(n, w, r0) for n, (w, r0) in self.local_shards().items()] + [(n, w, 0) for n, w in self.dp_tables().items()]
@@ -689,6 +691,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
         """Accepts, per table, either the local shard or the WHOLE table (rows are then cut at this rank's row
         offset, as the reference's tests load a global model into shards: test_model_parallel_base.py:92-122)."""
+        self._weights_epoch += 1  # a lookup prefetched before this load read the old tables
         targets = {n: (w, r0, False) for n, (w, r0) in self.local_shards().items()}
         targets.update({n: (w, 0, True) for n, w in self.dp_tables().items()})
         cfg = {c.name: c for c in self._embedding_bag_configs}
@@ -1073,6 +1076,7 @@ class ExplicitLookupStep:
                  early_replicated_lookup: bool = True) -> None:
         self.o, self.d = owner, dist_input
         self.halves = bool(halves and owner._exchange)  # two half-batch exchanges (finish_half / start_backward_half)
+        self.epoch = owner._weights_epoch  # a prefetched step is only good while nobody has rewritten the tables
         self.dp_rec = None
         self.state: Optional[_ExchangeState] = None
         self._grad: Optional[torch.Tensor] = None
@@ -1182,6 +1186,16 @@ class ExplicitLookupStep:
             else:
                 w.grad.add_(g)
             self.dp_rec = None
+
+    def discard(self) -> None:
+        """Drops a step that will not be used (a prefetched lookup made stale by a load_state_dict): drains its exchange."""
+        st = self.state
+        if st is not None:
+            for w in [st.work] + list(getattr(st, "_half_work", [])):
+                if w is not None:
+                    w.wait()
+            st.work = None
+        self.rec = self.dp_rec = None
 
     def finish_backward(self) -> None:
         grad = self.state.finish_backward() if self.state is not None else self._grad

@@ -17,15 +17,15 @@ from ..profiling import label
 from .model_parallel import DistributedModelParallel
 
 
-class _PipelinedEBC(torch.nn.Module):
-    """Stands in for a ShardedEmbeddingBagCollection during a pipelined step: forward() consumes the
-    input_dist result computed earlier on the data_dist stream (train_pipeline.py:193-243)."""
+class _PipelinedEBC:
+    """The pipelined forward of a ShardedEmbeddingBagCollection: consumes the input_dist result computed earlier on the
+    data_dist stream.  Installed the way the reference installs its PipelinedForward — `sharded.forward` is rewritten on
+    the INSTANCE (train_pipeline.py:193-243) — so the module tree, parameter names and state_dict keys stay what they were
+    before the pipeline touched the model (a wrapper module in the tree renamed every key under it)."""
 
     def __init__(self, sharded, pipeline: "TrainPipelineSparseDist") -> None:
-        super().__init__()
         self.sharded = sharded
         self.pipeline = pipeline
-        self.embedding_bag_configs = sharded.embedding_bag_configs
 
     def _dist_input(self, features):
         req = self.pipeline._requests.pop(id(self.sharded), None)
@@ -112,20 +112,14 @@ class TrainPipelineSparseDist:
         self._deferred_finish = bool(ok and os.environ.get("TORCHREC_AMD_DEFERRED_FINISH", "0") == "1")
 
     def _install(self) -> None:
-        root = self._model.module if isinstance(self._model, DistributedModelParallel) else self._model
-        ids = {id(s): s for s in self._sharded}
         self._wrappers: List[_PipelinedEBC] = []
-
-        def walk(m):
-            for name, child in list(m.named_children()):
-                if id(child) in ids:
-                    w = _PipelinedEBC(child, self)
-                    self._wrappers.append(w)
-                    setattr(m, name, w)
-                elif not isinstance(child, _PipelinedEBC):
-                    walk(child)
-
-        walk(root)
+        for s in self._sharded:
+            w = getattr(s, "_pipelined", None)
+            if w is None or w.pipeline is not self:
+                w = _PipelinedEBC(s, self)
+                s.forward = w.forward  # instance attribute: shadows the class's forward for nn.Module.__call__
+                s._pipelined = w       # explicit-step models reach compute_explicit() on the queued input dist through it
+            self._wrappers.append(w)
 
     def _prefetch_next_lookup(self):
         """Lookup + pooled all-to-all of batch i+1, enqueued behind the last backward launch of batch i (see

@@ -80,7 +80,7 @@ def _sort_hooks(ebc: nn.Module):
     """(defer, launch) callables of a collection that lets its caller place the backward sort, or (None, None)."""
     if _SORT_PLACEMENT != "head":
         return None, None
-    inner = getattr(ebc, "sharded", ebc)  # the train pipeline wraps sharded collections (train_pipeline._PipelinedEBC)
+    inner = getattr(ebc, "sharded", ebc)  # (a wrapper object that carries the collection as `.sharded`, if any)
     if hasattr(inner, "defer_backward_sort") and hasattr(inner, "launch_deferred_backward_sort"):
         return inner.defer_backward_sort, inner.launch_deferred_backward_sort
     return None, None
@@ -340,7 +340,7 @@ class DLRMTrain(nn.Module):
                             q.data = view
                             off += q.numel()
         ebc = m.sparse_arch.embedding_bag_collection
-        ebc = getattr(ebc, "sharded", ebc)  # a train pipeline may have wrapped it
+        ebc = getattr(ebc, "sharded", ebc)
         if half_batches is None:
             half_batches = _HALF_BATCHES == "1" or (_HALF_BATCHES == "auto" and B >= _HALF_BATCH_MIN)
         halves = bool(half_batches and flat_grads and B % 2 == 0 and getattr(ebc, "_exchange", False)
@@ -599,6 +599,11 @@ class DLRMTrain(nn.Module):
         kjt = batch.sparse_features
         pre = getattr(self, "_prefetched", None)
         object.__setattr__(self, "_prefetched", None)
+        if pre is not None and pre[0] is kjt and getattr(pre[1], "epoch", 0) != getattr(inner, "_weights_epoch", 0):
+            # the tables were rewritten (load_state_dict) after the prefetch: look up again, on the same distributed ids
+            pre[1].discard()
+            pre = (kjt, inner.compute_explicit(pre[1].d))
+            object.__setattr__(self, "prefetched_lookups", getattr(self, "prefetched_lookups", 0) - 1)
         if pre is not None and pre[0] is kjt:
             step = pre[1]  # looked up (and its all-to-all started) at the end of the previous step
             object.__setattr__(self, "prefetched_lookups", getattr(self, "prefetched_lookups", 0) + 1)
@@ -606,7 +611,8 @@ class DLRMTrain(nn.Module):
             if pre is not None:
                 raise RuntimeError("DLRMTrain: a lookup was prefetched for another batch than the one this step received; the "
                                    "owner of the pipeline must feed the batches in the order it announced them")
-            step = (ebc.compute_explicit(kjt) if hasattr(ebc, "sharded")
+            piped = getattr(ebc, "_pipelined", None)  # a train pipeline's forward on this collection (queued input dist)
+            step = (piped.compute_explicit(kjt) if piped is not None
                     else (ebc.compute_explicit(ebc.input_dist(kjt).wait()) if ebc.explicit_step_supported(kjt.stride()) else None))
         if step is None:
             return None
