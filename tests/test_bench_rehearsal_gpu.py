@@ -84,6 +84,9 @@ def test_bench_main_at_world_2_on_one_gpu_matches_world_1():
     assert plan["source"].startswith("pinned mixed plan") and d["config"]["local_batch"] == 32768
     assert d["binding"]["xgmi_bytes_per_rank_per_step"] > 0
     assert d["hip_graphs"] is True and d["hip_graphs_note"] == "on" and d["explicit_backward_steps"] == 8
+    # the N = 2 defaults at the global batch of 65 536: the exchange in two half-batches (auto from 32 768 samples per rank),
+    # the next step's lookup prefetched behind the embedding update with the late weight-gradient graphs behind it
+    assert d["half_batch_steps"] == 8 and d["prefetched_lookups"] == 7
     allk = d["roofline"]["all"]
     assert allk["tbe_fwd_short_kernel"]["launches"] >= 6 and allk["bwd_update_kernel"]["avg_us"] > 0
     c = d["checks"]
