@@ -328,6 +328,8 @@ def main(args):
             ebc_now = train_model.model.sparse_arch.embedding_bag_collection
             if hasattr(ebc_now, "set_output_buffer"):
                 ebc_now.set_output_buffer(None)
+            if hasattr(ebc_now, "set_replicated_grad_sink"):
+                ebc_now.set_replicated_grad_sink(None)
             torch.cuda.synchronize()
             hip_graphs = False
     model.init_data_parallel()

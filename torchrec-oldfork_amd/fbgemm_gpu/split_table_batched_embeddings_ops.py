@@ -1156,12 +1156,27 @@ class DenseTableBatchedEmbeddingBagsCodegen(_TBEBase):
             rec.prepared = self._prepare_or_defer(rec, indices, offsets, B, per_sample_weights is not None)
         return out, rec
 
-    def backward_no_autograd(self, rec: "LookupRecord", grad_out: torch.Tensor) -> torch.Tensor:
-        """The dense gradient of `.weights` for the lookup `rec` describes (what _DenseLookup.backward returns)."""
-        grad_w = torch.zeros_like(self.weights)
+    def backward_no_autograd(self, rec: "LookupRecord", grad_out: torch.Tensor,
+                             into: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The dense gradient of `.weights` for the lookup `rec` describes (what _DenseLookup.backward returns).
+        `into`: a persistent float32 buffer shaped like `.weights` (e.g. this parameter's slice of a flat gradient buffer)
+        that receives the gradient instead of a fresh tensor — no allocation, and the per-feature address table is built
+        once per buffer instead of by a kernel per step."""
+        if into is not None:
+            if (into.shape != self.weights.shape or into.dtype != torch.float32 or not into.is_contiguous()
+                    or into.device != self.weights.device):
+                raise RuntimeError("backward_no_autograd: `into` must be a contiguous float32 tensor shaped like .weights")
+            grad_w = into.zero_()
+            cached = getattr(self, "_dense_ptrs_cache", None)
+            if cached is None or cached[0] != grad_w.data_ptr():
+                cached = self._dense_ptrs_cache = (grad_w.data_ptr(), self._dense_grad_ptrs(grad_w))
+            ptrs = cached[1]
+        else:
+            grad_w = torch.zeros_like(self.weights)
+            ptrs = self._dense_grad_ptrs(grad_w)
         opt = OptimizerArgs(_OPT_DENSE_GRAD, 0.0, 0.0, 0.0, 0.0, 0.0, 1)
         self._backward_impl(grad_out, rec.indices, rec.offsets, rec.per_sample_weights, rec.B, opt,
-                            state0_override=self._dense_grad_ptrs(grad_w), prepared=rec.prepared, layout=rec.layout,
+                            state0_override=ptrs, prepared=rec.prepared, layout=rec.layout,
                             state0_aligned=grad_w.data_ptr() % 16 == 0)
         rec.prepared = None
         return grad_w

@@ -511,6 +511,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
         self._kjt_cache: Dict[Tuple, Any] = {}
         self._output_buffer: Optional[torch.Tensor] = None  # see set_output_buffer
         self.half_batch_exchange = False  # see set_half_batch_exchange
+        self._replicated_grad_sink: Optional[torch.Tensor] = None  # see set_replicated_grad_sink
         self._weights_epoch = 0  # bumped by everything that rewrites tables outside a train step (see ExplicitLookupStep.epoch)
         # ---- local tables + TBE ----------------------------------------------------------------
         self._local_tables: List[_LocalTable] = []
@@ -592,6 +593,14 @@ class ShardedEmbeddingBagCollection(nn.Module):
         segment, so that the segment reads the embeddings in place.  The caller owns the aliasing: the
         output of step i is overwritten by step i + 1."""
         self._output_buffer = buf
+
+    def set_replicated_grad_sink(self, buf: Optional[torch.Tensor]) -> None:
+        """A persistent float32 buffer shaped like the replicated tables' parameter (`_dp_module.weights`): the explicit
+        step's backward writes their dense gradient there and hands it out as `.grad` (DLRMTrain: the parameter's slice of
+        the flat gradient buffer that is all-reduced as a whole).  Requires zero_grad(set_to_none=True) between steps."""
+        if buf is not None and (self._dp_module is None or buf.shape != self._dp_module.weights.shape):
+            raise ValueError("set_replicated_grad_sink: the buffer must be shaped like the replicated tables' parameter")
+        self._replicated_grad_sink = buf
 
     def set_half_batch_exchange(self, on: bool) -> None:
         """compute_explicit() then exchanges the pooled embeddings (and their gradients) as two half-batches
@@ -1180,11 +1189,17 @@ class ExplicitLookupStep:
         o = self.o
         if self.dp_rec is not None:
             w = o._dp_module.weights
-            g = o._dp_module.backward_no_autograd(self.dp_rec, grad_out)
-            if w.grad is None:
-                w.grad = g
+            sink = o._replicated_grad_sink
+            if sink is not None and w.grad is None:
+                # the owner's persistent gradient buffer for the replicated tables (its slice of a flat, all-reduced
+                # buffer): written in place — no allocation, no address-table kernel, no copy into the flat buffer later
+                w.grad = o._dp_module.backward_no_autograd(self.dp_rec, grad_out, into=sink)
             else:
-                w.grad.add_(g)
+                g = o._dp_module.backward_no_autograd(self.dp_rec, grad_out)
+                if w.grad is None:
+                    w.grad = g
+                else:
+                    w.grad.add_(g)
             self.dp_rec = None
 
     def discard(self) -> None:

@@ -424,6 +424,10 @@ class DLRMTrain(nn.Module):
                 state["fired"] += 1
 
             state["fired"] = 0
+            if hasattr(ebc, "set_replicated_grad_sink"):
+                dp = getattr(ebc, "_dp_module", None)
+                sink = next((v for q, v in zip(extras, extra_views) if dp is not None and q is dp.weights), None)
+                ebc.set_replicated_grad_sink(sink)
             g_head.after_backward = reduce_head
             g_dense.after_backward = dense_done
             object.__setattr__(self, "_flat_dense", state)
