@@ -67,7 +67,9 @@ _DEFER_WGRAD = os.environ.get("TORCHREC_AMD_DEFER_WGRAD", "1") != "0"
 # this-many Linear layers are captured into a third graph that the explicit step replays AFTER it has started the NEXT step's
 # lookup + pooled all-to-all (the rest stays behind this step's gradient all-to-all).  The forward all-to-all then has the
 # same kind of cover the gradient all-to-all always had, instead of the bottom MLP's forward only.  0 = off.
-_WGRAD_LATE_LAYERS = int(os.environ.get("TORCHREC_AMD_WGRAD_LATE_LAYERS", "2"))
+# (default 3 of the 5 head layers: with emulated links 2 / 3 / 4 measure 1.710 / 1.720 / 1.792 ms at the 8-GPU shape and
+# 3.179 / 3.105 / 3.146 at the 4-GPU one: profiles/r03_rehearsal_late_wgrads.txt)
+_WGRAD_LATE_LAYERS = int(os.environ.get("TORCHREC_AMD_WGRAD_LATE_LAYERS", "3"))
 _HALF_BATCHES = os.environ.get("TORCHREC_AMD_HALF_BATCHES", "auto")
 _HALF_BATCH_MIN = int(os.environ.get("TORCHREC_AMD_HALF_BATCH_MIN", "32768"))
 
