@@ -143,3 +143,9 @@ def test_late_weight_gradients_behind_the_prefetched_lookup_change_no_bit():
     assert late["checks"]["loss_first"] == plain["checks"]["loss_first"]
     assert late["checks"]["loss_last"] == plain["checks"]["loss_last"]
     assert late["checks"]["param_checksum"] == plain["checks"]["param_checksum"]
+    # the same again with the exchange's unpack / pack captured into the head segment's graphs (persistent receive /
+    # send buffers; opt-in): the same kernels on the same data
+    graphed = _run(dict(env, TORCHREC_AMD_GRAPH_EXCHANGE="1"), "--global-batch", "4096")
+    assert graphed["hip_graphs_note"] == "on" and graphed["explicit_backward_steps"] == 7
+    assert graphed["checks"]["loss_last"] == plain["checks"]["loss_last"]
+    assert graphed["checks"]["param_checksum"] == plain["checks"]["param_checksum"]

@@ -13,6 +13,8 @@ _def.define("pooled_exchange_unpack_into(Tensor recv, Tensor feat_out_col, Tenso
             "Tensor slab_offset, Tensor slab_stride, int B_local, int D_total, bool vec, float scale, Tensor(a!) out) -> Tensor(a!)")
 _def.define("pooled_exchange_pack(Tensor grad, Tensor feat_out_col, Tensor feat_src, Tensor feat_slab_col, "
             "Tensor slab_offset, Tensor slab_stride, int numel, bool vec, float scale) -> Tensor")
+_def.define("pooled_exchange_pack_into(Tensor grad, Tensor feat_out_col, Tensor feat_src, Tensor feat_slab_col, "
+            "Tensor slab_offset, Tensor slab_stride, bool vec, float scale, Tensor(a!) send) -> Tensor(a!)")
 _def.define("a2a_pooled_unpack(Tensor recv, Tensor dim_sum_per_rank, int B_local, int D_total, bool vec, float scale) -> Tensor")
 _def.define("a2a_pooled_pack(Tensor grad, Tensor dim_sum_per_rank, bool vec, float scale) -> Tensor")
 _def.define("relu_backward_bias_grad(Tensor grad_out, Tensor act) -> (Tensor, Tensor)")
@@ -208,6 +210,22 @@ def _pack(grad, feat_out_col, feat_src, feat_slab_col, slab_offset, slab_stride,
     return send
 
 
+def _pack_into(grad, feat_out_col, feat_src, feat_slab_col, slab_offset, slab_stride, vec, scale, send):
+    """pooled_exchange_pack into the caller's (persistent) send buffer — what a captured backward graph needs."""
+    dev = require_gpu(grad, feat_out_col, feat_src, feat_slab_col, slab_offset, slab_stride, send)
+    if grad.dim() != 2 or not grad.is_contiguous() or grad.dtype != torch.float32:
+        raise RuntimeError("pooled_exchange_pack_into: grad must be a contiguous float32 [B_local, D_total] matrix")
+    if send.dtype != torch.float32 or not send.is_contiguous():
+        raise RuntimeError("pooled_exchange_pack_into: send must be a contiguous float32 buffer")
+    B_local, D_total = grad.shape
+    with torch.cuda.device(dev):
+        check(_lib.load().tbe_pooled_exchange_pack(
+            ptr(grad), ptr(send), ptr(feat_out_col), ptr(feat_src), ptr(feat_slab_col), ptr(slab_offset),
+            ptr(slab_stride), feat_src.numel(), slab_offset.numel(), B_local, D_total, int(vec), scale,
+            stream_ptr(dev)), "tbe_pooled_exchange_pack")
+    return send
+
+
 _impl.impl("relu_backward_bias_grad", _relu_backward_bias_grad)
 _impl.impl("weighted_colsum", _weighted_colsum)
 _impl.impl("copy_rows", _copy_rows)
@@ -218,5 +236,6 @@ _impl.impl("bce_with_logits", _bce_with_logits)
 _impl.impl("pooled_exchange_unpack", _unpack)
 _impl.impl("pooled_exchange_unpack_into", _unpack_into)
 _impl.impl("pooled_exchange_pack", _pack)
+_impl.impl("pooled_exchange_pack_into", _pack_into)
 _impl.impl("a2a_pooled_unpack", _simple_unpack)
 _impl.impl("a2a_pooled_pack", _simple_pack)

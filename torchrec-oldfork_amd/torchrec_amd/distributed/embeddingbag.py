@@ -207,10 +207,14 @@ class _ExchangeState:
         self._dest: Optional[torch.Tensor] = None
         self._half_bwd_work: List[Any] = []
         self._half_send_keepalive: List[torch.Tensor] = []
+        self.static = None
 
     def start_forward(self, emb: torch.Tensor) -> None:
         o, lay = self.o, self.lay
-        self.recv_fwd = torch.empty(lay["recv_numel"], dtype=torch.float32, device=emb.device)
+        static = o._static_exchange if (o._static_exchange is not None and o._static_exchange["B"] == self.B) else None
+        self.static = static  # persistent receive / send buffers: the owner's graphs unpack / pack (set_graph_exchange)
+        self.recv_fwd = (static["recv_fwd"] if static is not None
+                         else torch.empty(lay["recv_numel"], dtype=torch.float32, device=emb.device))
         with label("## alltoall_fwd_single ##"):  # comm_ops.py:489
             self.work = dist.all_to_all_single(self.recv_fwd, emb.reshape(-1), output_split_sizes=lay["recv_splits"],
                                                input_split_sizes=lay["send_splits"], group=o._pg, async_op=True)
@@ -225,6 +229,20 @@ class _ExchangeState:
             self._dest = (o._alias_output_buffer(self.B) if buf is not None and buf.numel() == self.B * o._D_total
                           else torch.empty((self.B, o._D_total), dtype=torch.float32, device=self.recv_fwd.device))
         return self._dest
+
+    def wait_forward(self) -> None:
+        """Static-exchange mode: the current stream waits for the pooled all-to-all; the owner's forward graph unpacks."""
+        with label("## alltoall_fwd_wait ##"):
+            self.work.wait()
+        self.work = None
+
+    def start_backward_packed(self) -> None:
+        """Static-exchange mode: the owner's backward graph has packed the gradient into the persistent send buffer."""
+        o, lay, st = self.o, self.lay, self.static
+        self.grad_recv = st["grad_recv"]
+        with label("## alltoall_bwd_single ##"):  # comm_ops.py:591
+            self.bwd_work = dist.all_to_all_single(self.grad_recv, st["send_bwd"], output_split_sizes=lay["send_splits"],
+                                                   input_split_sizes=lay["recv_splits"], group=o._pg, async_op=True)
 
     def finish_forward(self) -> torch.Tensor:
         with label("## alltoall_fwd_wait ##"):
@@ -512,6 +530,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
         self._output_buffer: Optional[torch.Tensor] = None  # see set_output_buffer
         self.half_batch_exchange = False  # see set_half_batch_exchange
         self._replicated_grad_sink: Optional[torch.Tensor] = None  # see set_replicated_grad_sink
+        self._static_exchange: Optional[Dict[str, Any]] = None  # see set_graph_exchange
         self._weights_epoch = 0  # bumped by everything that rewrites tables outside a train step (see ExplicitLookupStep.epoch)
         # ---- local tables + TBE ----------------------------------------------------------------
         self._local_tables: List[_LocalTable] = []
@@ -601,6 +620,38 @@ class ShardedEmbeddingBagCollection(nn.Module):
         if buf is not None and (self._dp_module is None or buf.shape != self._dp_module.weights.shape):
             raise ValueError("set_replicated_grad_sink: the buffer must be shaped like the replicated tables' parameter")
         self._replicated_grad_sink = buf
+
+    def set_graph_exchange(self, batch_size: Optional[int]):
+        """Static-exchange mode for compute_explicit() at this per-rank batch size (None = off): the pooled all-to-alls
+        use PERSISTENT receive / send buffers and the step neither unpacks nor packs — the owner captures those two kernels
+        into its own HIP graphs (the returned callables: `unpack()` writes the sharded features' columns of the output
+        buffer from the receive buffer, `pack(grad)` fills the send buffer from the [B, sum D] gradient), so that they cost
+        no eager launch in a stretch of the step where the host is what the GPU waits for.  One step at a time uses the
+        buffers, which the explicit step guarantees (also with the next lookup prefetched: its all-to-all is ordered
+        behind this step's unpack)."""
+        if batch_size is None or not self._exchange:
+            self._static_exchange = None
+            return None
+        B = int(batch_size)
+        lay = self._exchange_layout(B)
+        dev = self._device
+        st = {"B": B, "recv_fwd": torch.zeros(lay["recv_numel"], dtype=torch.float32, device=dev),
+              "send_bwd": torch.zeros(lay["recv_numel"], dtype=torch.float32, device=dev),
+              "grad_recv": torch.zeros(lay["send_numel"], dtype=torch.float32, device=dev)}
+        self._static_exchange = st
+        scale = 1.0 / self._world_size if GRADIENT_DIVISION else 1.0
+
+        def unpack() -> None:
+            torch.ops.tbe_hip.pooled_exchange_unpack_into(
+                st["recv_fwd"], lay["feat_out_col"], lay["feat_src"], lay["feat_slab_col"], lay["slab_offset"],
+                lay["slab_stride"], B, self._D_total, self._vec_ok, 1.0, self._alias_output_buffer(B))
+
+        def pack(grad: torch.Tensor) -> None:
+            torch.ops.tbe_hip.pooled_exchange_pack_into(
+                grad.view(B, self._D_total), lay["feat_out_col"], lay["feat_src"], lay["feat_slab_col"], lay["slab_offset"],
+                lay["slab_stride"], self._vec_ok, scale, st["send_bwd"])
+
+        return unpack, pack
 
     def set_half_batch_exchange(self, on: bool) -> None:
         """compute_explicit() then exchanges the pooled embeddings (and their gradients) as two half-batches
@@ -1132,7 +1183,11 @@ class ExplicitLookupStep:
     def finish(self) -> torch.Tensor:
         """[B_local, sum D] pooled embeddings in the collection's key order, inside the output buffer."""
         self._late_dp_lookup()
-        out = self.state.finish_forward() if self.state is not None else self._out
+        if self.state is not None and self.state.static is not None:
+            self.state.wait_forward()  # the owner's forward graph unpacks the persistent receive buffer
+            out = self.state.output_destination()
+        else:
+            out = self.state.finish_forward() if self.state is not None else self._out
         self._launch_late_dp_sort()
         return out
 
@@ -1179,7 +1234,9 @@ class ExplicitLookupStep:
     def start_backward(self, grad_out: torch.Tensor) -> None:
         """grad_out: [B_local, sum D], contiguous.  Packs and starts the gradient all-to-all (if any), and runs the
         replicated tables' backward (their dense gradient lands in `.grad` of the module's weights) meanwhile."""
-        if self.state is not None:
+        if self.state is not None and self.state.static is not None:
+            self.state.start_backward_packed()  # the owner's backward graph has filled the persistent send buffer
+        elif self.state is not None:
             self.state.start_backward(grad_out)
         else:
             self._grad = grad_out

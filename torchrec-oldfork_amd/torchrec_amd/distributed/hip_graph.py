@@ -67,9 +67,13 @@ class GraphedSegment(nn.Module):
 
     def __init__(self, module: nn.Module, sample_inputs: Sequence[torch.Tensor],
                  input_buffers: Optional[Sequence[Optional[torch.Tensor]]] = None, warmup: int = 3,
-                 pool=None) -> None:
+                 pool=None, pre_forward=None) -> None:
+        """`pre_forward`: a callable captured at the START of the forward graph (and run in the warm-up) — e.g. the kernel
+        that unpacks a persistent receive buffer into one of the static inputs, so that it costs no eager launch.
+        Its counterpart is capture_backward(post_backward=)."""
         super().__init__()
         self.module = module
+        self._pre_forward = pre_forward
         self.n_inputs = len(sample_inputs)
         input_buffers = list(input_buffers) if input_buffers is not None else [None] * self.n_inputs
         self.static_inputs: List[torch.Tensor] = []
@@ -102,6 +106,9 @@ class GraphedSegment(nn.Module):
         self._pool_handle = self._pool
 
     def _call(self) -> Tuple[torch.Tensor, ...]:
+        if self._pre_forward is not None:
+            with torch.no_grad():
+                self._pre_forward()
         out = self.module(*self.static_inputs)
         return tuple(out) if isinstance(out, (tuple, list)) else (out,)
 
@@ -113,7 +120,7 @@ class GraphedSegment(nn.Module):
 
     def capture_backward(self, grad_output_buffers: Optional[Sequence[Optional[torch.Tensor]]] = None,
                          param_grad_sinks: Optional[Sequence[torch.Tensor]] = None, sink_scale: float = 1.0,
-                         defer_wgrad: bool = False, late_params: int = 0) -> None:
+                         defer_wgrad: bool = False, late_params: int = 0, post_backward=None) -> None:
         """Captures d(outputs)/d(inputs, parameters).  `grad_output_buffers[i]` lets a downstream
         segment's static input-gradient buffer double as this segment's output-gradient buffer.
         `param_grad_sinks[j]` (one per parameter, in `parameters()` order): the graph itself writes
@@ -126,7 +133,9 @@ class GraphedSegment(nn.Module):
         `late_params` (with defer_wgrad and sinks): the gradients of the FIRST `late_params` parameters (in `parameters()`
         order: the first layers of an MLP) go into a THIRD graph, `bwd_graph3`, the rest stay in `bwd_graph2` — an owner
         can then put one part behind the gradient all-to-all and the other behind the NEXT step's prefetched forward
-        all-to-all (models/dlrm.py).  `_Replay.backward` replays all three back to back."""
+        all-to-all (models/dlrm.py).  `_Replay.backward` replays all three back to back.
+        `post_backward(input_grads)`: a callable captured at the END of the first backward graph, behind the input
+        gradients — e.g. the kernel that packs the pooled-embedding gradient into a persistent send buffer."""
         from ..modules.mlp import _DeferredWgrad
 
         outs = self.static_outputs
@@ -229,6 +238,9 @@ class GraphedSegment(nn.Module):
                 _DeferredWgrad.partials_ok = False
             if param_grad_sinks is not None and not stash:
                 write_sinks(grads[n_in:])
+            if post_backward is not None:
+                with torch.no_grad():
+                    post_backward(grads[:n_in])
         if stash:
             index = {id(p): n_in + j for j, p in enumerate(self._params)}
 

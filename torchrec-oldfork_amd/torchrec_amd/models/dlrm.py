@@ -70,6 +70,11 @@ _DEFER_WGRAD = os.environ.get("TORCHREC_AMD_DEFER_WGRAD", "1") != "0"
 # (default 3 of the 5 head layers: with emulated links 2 / 3 / 4 measure 1.710 / 1.720 / 1.792 ms at the 8-GPU shape and
 # 3.179 / 3.105 / 3.146 at the 4-GPU one: profiles/r03_rehearsal_late_wgrads.txt)
 _WGRAD_LATE_LAYERS = int(os.environ.get("TORCHREC_AMD_WGRAD_LATE_LAYERS", "3"))
+# whole-batch explicit step with an exchange: unpack / pack captured into the head segment's graphs instead of two eager
+# launches (persistent receive / send buffers).  Opt-in: bit-identical, the two launch gaps (8 + 7 us) do disappear, and the
+# step gets no faster — 1.732 vs 1.695 ms at 8192 per rank, 2.849 vs 2.854 at 16 384 (the host, freed earlier, starts the
+# next input dist earlier, and its kernels then share the chip with the head's forward GEMMs: + 50 us of GEMM time)
+_GRAPH_EXCHANGE = os.environ.get("TORCHREC_AMD_GRAPH_EXCHANGE", "0") == "1"
 _HALF_BATCHES = os.environ.get("TORCHREC_AMD_HALF_BATCHES", "auto")
 _HALF_BATCH_MIN = int(os.environ.get("TORCHREC_AMD_HALF_BATCH_MIN", "32768"))
 
@@ -348,6 +353,8 @@ class DLRMTrain(nn.Module):
         halves = bool(half_batches and flat_grads and B % 2 == 0 and getattr(ebc, "_exchange", False)
                       and hasattr(ebc, "set_half_batch_exchange") and _EXPLICIT_STEP)
         g_dense = GraphedSegment(m.dense_arch, [torch.randn(B, dense_in, device=dev)])
+        if halves and hasattr(ebc, "set_graph_exchange"):
+            ebc.set_graph_exchange(None)
         if halves:
             # whole-batch buffers the two head segments share by halves: pooled embeddings (the collection's output
             # buffer), labels, and the gradients w.r.t. the bottom-MLP output / the pooled embeddings
@@ -369,11 +376,23 @@ class DLRMTrain(nn.Module):
                     m.inter_arch.grad_sinks = None
             g_head = heads[1]
         else:
+            # static-exchange mode (flat gradients + explicit step + a collection that exchanges): the unpack of the pooled
+            # all-to-all's receive buffer is the FIRST kernel of the head's forward graph and the pack of the gradient
+            # into the send buffer the LAST of its backward graph, instead of two eager launches per step
+            hooks = None
+            if (flat_grads and _EXPLICIT_STEP and _GRAPH_EXCHANGE and getattr(ebc, "_exchange", False)
+                    and hasattr(ebc, "set_graph_exchange")):
+                pooled = torch.zeros(B, F, D, device=dev)
+                ebc.set_output_buffer(pooled)
+                hooks = ebc.set_graph_exchange(B)
+            elif hasattr(ebc, "set_graph_exchange"):
+                ebc.set_graph_exchange(None)
             g_head = GraphedSegment(
                 head, [g_dense.static_outputs[0].detach().requires_grad_(True),
                        torch.randn(B, F, D, device=dev).requires_grad_(True),
                        torch.randint(0, 2, (B,), device=dev)],  # int64, as the data loader delivers them
-                input_buffers=[g_dense.static_outputs[0], None, None], pool=g_dense._pool)
+                input_buffers=[g_dense.static_outputs[0], pooled if hooks is not None else None, None], pool=g_dense._pool,
+                pre_forward=hooks[0] if hooks is not None else None)
         head_sinks = dense_sinks = None
         scale = 1.0
         if flat_grads:
@@ -466,13 +485,16 @@ class DLRMTrain(nn.Module):
             state["n_late"] = sum(q.numel() for q in g_head._params[:late]) if heads[1].bwd_graph3 is not None else 0
             g_dense.capture_backward([half["gd"]], param_grad_sinks=dense_sinks, sink_scale=scale, defer_wgrad=_DEFER_WGRAD)
             object.__setattr__(self, "_half", half)
+            object.__setattr__(self, "_graph_exchange", False)
         else:
-            if hasattr(ebc, "set_output_buffer"):
+            if hasattr(ebc, "set_output_buffer") and hooks is None:
                 ebc.set_output_buffer(g_head.static_input(1).detach())
             # flat mode: the head's weight gradients go into a second graph that the explicit step replays after it has
             # started the embedding-gradient all-to-all (modules/mlp.py _DeferredWgrad)
             g_head.capture_backward(param_grad_sinks=head_sinks, sink_scale=scale, defer_wgrad=flat_grads and _DEFER_WGRAD,
-                                    late_params=late)
+                                    late_params=late,
+                                    post_backward=(lambda gin: hooks[1](gin[1])) if hooks is not None else None)
+            object.__setattr__(self, "_graph_exchange", hooks is not None)
             if flat_grads:
                 state["n_late"] = sum(q.numel() for q in g_head._params[:late]) if g_head.bwd_graph3 is not None else 0
             # the head's gradient w.r.t. the bottom-MLP output doubles as the bottom segment's grad_output buffer
@@ -750,6 +772,9 @@ class DLRMTrain(nn.Module):
             if getattr(self, "_half", None) is not None:
                 raise RuntimeError("DLRMTrain: graphs captured with half_batches=True serve the explicit step only (run the "
                                    "model under TrainPipelineSparseDist, or capture with half_batches=False)")
+            if getattr(self, "_graph_exchange", False):
+                raise RuntimeError("DLRMTrain: these graphs unpack / pack the pooled exchange themselves and serve the explicit "
+                                   "step only (run the model under TrainPipelineSparseDist, or set TORCHREC_AMD_GRAPH_EXCHANGE=0)")
             defer, launch = _sort_hooks(self.model.sparse_arch.embedding_bag_collection)
             if defer is not None:
                 defer(True)
