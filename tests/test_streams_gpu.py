@@ -53,3 +53,46 @@ def test_tbe_backward_sort_stream_is_probed():
     side = m._side_stream
     if side is not None:  # the overlapped sort was used
         assert not shares_hw_queue(side, torch.cuda.default_stream())
+
+
+def _second_group_worker(rank, port, ret):
+    import os
+
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    from torchrec_amd.distributed.comm import init_rccl_process_group, new_rccl_group
+
+    init_rccl_process_group(dev, rank=0, world_size=1)
+    try:
+        dense_pg = new_rccl_group(dist.group.WORLD)  # what DLRMTrain.capture_hip_graphs creates at N > 1
+        a = torch.arange(1 << 20, dtype=torch.float32, device=dev)
+        out = torch.empty_like(a)
+        w1 = dist.all_to_all_single(out, a, [a.numel()], [a.numel()], async_op=True)  # first communicator
+        g = torch.ones(1 << 16, device=dev)
+        w2 = dist.all_reduce(g, group=dense_pg, async_op=True)                      # second one, concurrently
+        w1.wait()
+        w2.wait()
+        torch.cuda.synchronize()
+        ret[0] = (bool(torch.equal(out, a)), float(g.sum()), dist.get_world_size(dense_pg))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_second_rccl_communicator_for_the_dense_all_reduces():
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from _results import ResultStore
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ret = ResultStore()
+    mp.spawn(_second_group_worker, args=(port, ret), nprocs=1, join=True)
+    assert ret[0] == (True, float(1 << 16), 1)

@@ -27,3 +27,11 @@ def rccl_options(high_priority: Optional[bool] = None):
 def init_rccl_process_group(device: torch.device, high_priority: Optional[bool] = None, **kwargs) -> None:
     """`dist.init_process_group("nccl", device_id=device, ...)` with the collective stream on its own hardware queue."""
     dist.init_process_group("nccl", device_id=device, pg_options=rccl_options(high_priority), **kwargs)
+
+
+def new_rccl_group(process_group=None, high_priority: Optional[bool] = None):
+    """A second communicator over the ranks of `process_group` (default: the world), with its own (high-priority) collective
+    stream: collectives issued on it never queue behind those of the first one — DLRMTrain puts its dense gradient
+    all-reduces there, clear of the pooled all-to-alls.  Collective: every rank of the default group must call it."""
+    ranks = dist.get_process_group_ranks(process_group if process_group is not None else dist.group.WORLD)
+    return dist.new_group(ranks=ranks, pg_options=rccl_options(high_priority))

@@ -404,9 +404,9 @@ class DLRMTrain(nn.Module):
             if world > 1 and dist.get_backend(process_group) == "nccl" and os.environ.get("TORCHREC_AMD_DENSE_PG", "1") == "1":
                 # the dense all-reduces get a communicator (and stream) of their own: on the collection's they would queue
                 # behind a pooled all-to-all that is waiting for its links (the prefetched one, above all)
-                from ..distributed.comm import rccl_options
+                from ..distributed.comm import new_rccl_group
 
-                dense_pg = dist.new_group(ranks=dist.get_process_group_ranks(process_group), pg_options=rccl_options())
+                dense_pg = new_rccl_group(process_group)
             graphed = {id(q) for q in list(g_head._params) + list(g_dense._params)}
             # every other trainable dense parameter of the model (the replicated tiny tables of a sharded
             # collection): its gradient arrives through autograd and joins the flat buffer after backward
