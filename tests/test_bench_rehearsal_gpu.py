@@ -143,6 +143,11 @@ def test_late_weight_gradients_behind_the_prefetched_lookup_change_no_bit():
     assert late["checks"]["loss_first"] == plain["checks"]["loss_first"]
     assert late["checks"]["loss_last"] == plain["checks"]["loss_last"]
     assert late["checks"]["param_checksum"] == plain["checks"]["param_checksum"]
+    # the same again with the dense gradient all-reduces of an N > 1 run ISSUED (head slice without the late part, the rest,
+    # the late part; on their own RCCL communicator) although one rank needs none: the call sequence of a real rank
+    forced = _run(dict(env, TORCHREC_AMD_FORCE_DENSE_REDUCE="1"), "--global-batch", "4096")
+    assert forced["checks"]["loss_last"] == plain["checks"]["loss_last"]
+    assert forced["checks"]["param_checksum"] == plain["checks"]["param_checksum"]
     # the same again with the exchange's unpack / pack captured into the head segment's graphs (persistent receive /
     # send buffers; opt-in): the same kernels on the same data
     graphed = _run(dict(env, TORCHREC_AMD_GRAPH_EXCHANGE="1"), "--global-batch", "4096")

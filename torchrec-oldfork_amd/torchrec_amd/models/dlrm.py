@@ -401,7 +401,10 @@ class DLRMTrain(nn.Module):
             world = dist.get_world_size(process_group) if process_group is not None else 1
             scale = 1.0 / world
             dense_pg = process_group
-            if world > 1 and dist.get_backend(process_group) == "nccl" and os.environ.get("TORCHREC_AMD_DENSE_PG", "1") == "1":
+            # TORCHREC_AMD_FORCE_DENSE_REDUCE=1 (rehearsal of the N > 1 path on one rank): issue the dense all-reduces — and
+            # create their communicator — although a one-rank group needs none
+            reduce = world > 1 or (process_group is not None and os.environ.get("TORCHREC_AMD_FORCE_DENSE_REDUCE") == "1")
+            if reduce and dist.get_backend(process_group) == "nccl" and os.environ.get("TORCHREC_AMD_DENSE_PG", "1") == "1":
                 # the dense all-reduces get a communicator (and stream) of their own: on the collection's they would queue
                 # behind a pooled all-to-all that is waiting for its links (the prefetched one, above all)
                 from ..distributed.comm import new_rccl_group
@@ -428,15 +431,15 @@ class DLRMTrain(nn.Module):
             extra_views = views(extras, n_head + n_dense)
             state = {"flat": flat, "flat_param": flat_param, "params": list(g_head._params) + list(g_dense._params) + extras,
                      "views": head_sinks + dense_sinks + extra_views, "extras": list(zip(extras, extra_views)),
-                     "n_head": n_head, "works": [], "pg": dense_pg, "world": world, "scale": scale}
+                     "n_head": n_head, "works": [], "pg": dense_pg, "world": world, "scale": scale, "reduce": reduce}
 
             def reduce_head():  # the head's backward runs first: its slice overlaps the rest of backward
                 state["fired"] += 1
-                if state["world"] > 1:  # (without the late part: its gradients do not exist yet, reduce_late() follows)
+                if state["reduce"]:  # (without the late part: its gradients do not exist yet, reduce_late() follows)
                     state["works"].append(dist.all_reduce(flat[state.get("n_late", 0):n_head], group=state["pg"], async_op=True))
 
             def reduce_late():
-                if state["world"] > 1 and state.get("n_late", 0):
+                if state["reduce"] and state.get("n_late", 0):
                     state["works"].append(dist.all_reduce(flat[:state["n_late"]], group=state["pg"], async_op=True))
 
             state["reduce_late"] = reduce_late
@@ -542,7 +545,7 @@ class DLRMTrain(nn.Module):
                 torch.mul(q.grad, st["scale"], out=v)
             elif st["scale"] != 1.0:
                 v.mul_(st["scale"])  # autograd accumulated in place (zero_grad(set_to_none=False))
-        if st["world"] > 1:
+        if st["reduce"]:
             st["works"].append(dist.all_reduce(st["flat"][st["n_head"]:], group=st["pg"], async_op=True))
         st["rest_started"] = True
 
@@ -574,7 +577,7 @@ class DLRMTrain(nn.Module):
                     torch.mul(q.grad, st["scale"], out=v)
                 elif st["scale"] != 1.0:
                     v.mul_(st["scale"])
-            if st["world"] > 1:
+            if st["reduce"]:
                 st["works"].append(dist.all_reduce(st["flat"], group=st["pg"], async_op=True))
         else:
             self._start_rest_reduce(st)
