@@ -435,8 +435,10 @@ class DLRMTrain(nn.Module):
 
             def reduce_head():  # the head's backward runs first: its slice overlaps the rest of backward
                 state["fired"] += 1
-                if state["reduce"]:  # (without the late part: its gradients do not exist yet, reduce_late() follows)
-                    state["works"].append(dist.all_reduce(flat[state.get("n_late", 0):n_head], group=state["pg"], async_op=True))
+                # with a late part (its gradients do not exist yet) what is left of the head's slice is two small layers:
+                # they ride with the rest of the buffer (_start_rest_reduce) instead of paying for a collective of their own
+                if state["reduce"] and not state.get("n_late", 0):
+                    state["works"].append(dist.all_reduce(flat[:n_head], group=state["pg"], async_op=True))
 
             def reduce_late():
                 if state["reduce"] and state.get("n_late", 0):
@@ -546,7 +548,8 @@ class DLRMTrain(nn.Module):
             elif st["scale"] != 1.0:
                 v.mul_(st["scale"])  # autograd accumulated in place (zero_grad(set_to_none=False))
         if st["reduce"]:
-            st["works"].append(dist.all_reduce(st["flat"][st["n_head"]:], group=st["pg"], async_op=True))
+            lo = st["n_late"] if st.get("n_late", 0) else st["n_head"]  # (see reduce_head)
+            st["works"].append(dist.all_reduce(st["flat"][lo:], group=st["pg"], async_op=True))
         st["rest_started"] = True
 
     def finish_dense_grads(self) -> None:
