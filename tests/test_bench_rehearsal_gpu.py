@@ -84,9 +84,8 @@ def test_bench_main_at_world_2_on_one_gpu_matches_world_1():
     assert plan["source"].startswith("pinned mixed plan") and d["config"]["local_batch"] == 32768
     assert d["binding"]["xgmi_bytes_per_rank_per_step"] > 0
     assert d["hip_graphs"] is True and d["hip_graphs_note"] == "on" and d["explicit_backward_steps"] == 8
-    # the N = 2 defaults at the global batch of 65 536: the exchange in two half-batches (auto from 32 768 samples per rank),
-    # the next step's lookup prefetched behind the embedding update with the late weight-gradient graphs behind it
-    assert d["half_batch_steps"] == 8 and d["prefetched_lookups"] == 7
+    # the N = 2 default at the global batch of 65 536: the exchange in two half-batches (auto from 32 768 samples per rank)
+    assert d["half_batch_steps"] == 8 and d["prefetched_lookups"] == 0  # (no late weight gradients in half-batch mode)
     allk = d["roofline"]["all"]
     assert allk["tbe_fwd_short_kernel"]["launches"] >= 6 and allk["bwd_update_kernel"]["avg_us"] > 0
     c = d["checks"]
@@ -121,7 +120,9 @@ def test_bench_rehearsal_with_the_exchange_in_two_half_batches():
     env = {"TORCHREC_AMD_FORCE_EXCHANGE": "1", "TORCHREC_AMD_FORCE_DP": "1", "MASTER_PORT": "29563",
            "TORCHREC_AMD_REHEARSAL_LINK_US": "50"}
     whole = _run(dict(env, TORCHREC_AMD_HALF_BATCHES="0"), "--global-batch", "4096")
-    halves = _run(dict(env, TORCHREC_AMD_HALF_BATCHES="1"), "--global-batch", "4096")
+    # (with two late weight-gradient layers and the prefetch behind them: the half-batch step's own version of both)
+    halves = _run(dict(env, TORCHREC_AMD_HALF_BATCHES="1", TORCHREC_AMD_WGRAD_LATE_LAYERS="2"), "--global-batch", "4096")
+    assert halves["prefetched_lookups"] == 6
     assert whole["half_batch_steps"] == 0 and halves["half_batch_steps"] == 7 == halves["explicit_backward_steps"]
     assert halves["checks"]["sort_giveups"] == 0 and halves["checks"]["bounds_check_errors"] == 0
     for k in ("loss_first", "loss_last"):
@@ -137,6 +138,7 @@ def test_late_weight_gradients_behind_the_prefetched_lookup_change_no_bit():
     the dense optimizer has updated them."""
     env = {"TORCHREC_AMD_FORCE_EXCHANGE": "1", "TORCHREC_AMD_FORCE_DP": "1", "MASTER_PORT": "29564"}
     plain = _run(dict(env, TORCHREC_AMD_WGRAD_LATE_LAYERS="0", TORCHREC_AMD_PREFETCH_LOOKUP="0"), "--global-batch", "4096")
+    env = dict(env, TORCHREC_AMD_WGRAD_LATE_LAYERS="3")  # (auto keeps the late graph for per-rank batches of 16 384+)
     late = _run(env, "--global-batch", "4096")
     assert late["explicit_backward_steps"] == plain["explicit_backward_steps"] == 7
     assert late["prefetched_lookups"] > 0 and plain["prefetched_lookups"] == 0

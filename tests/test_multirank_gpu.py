@@ -458,6 +458,7 @@ def _e2e_run(model, opt, keys, batches, rank, W, dev, hip_graphs=False):
 
 
 def _e2e_worker(rank, W, port, ret, hip_graphs=False):
+    os.environ["TORCHREC_AMD_WGRAD_LATE_LAYERS"] = "2"  # flat modes: with the late weight-gradient graph and its all-reduce
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)

@@ -7,6 +7,8 @@ HIP graphs, the explicit step, the flat-gradient all-reduce (gloo reduces device
 `bench.py` with TORCHREC_AMD_BENCH_BACKEND=gloo and by tests/test_multirank_gpu.py; never on a real multi-GPU run
 (`nccl` = RCCL there, untouched).  The timings of such a run are NOT multi-GPU timings: all ranks share one GPU's
 CUs and HBM and the exchange crosses the host."""
+import os
+
 import torch
 import torch.distributed as dist
 from fbgemm_gpu._streams import side_stream
@@ -119,5 +121,28 @@ def emulate_link_time(fwd_us: float, full_bytes: int = 0) -> None:
                            list(output_tensor_list) + list(input_tensor_list), nbytes, async_op)
 
     dist.all_to_all = all_to_all
+
+    # dense all-reduces (TORCHREC_AMD_FORCE_DENSE_REDUCE issues them on one rank): 20 us of latency + bytes at an algorithm
+    # bandwidth, on a stream of their own (they use their own communicator in the product: models/dlrm.py)
+    ar_gbs = float(os.environ.get("TORCHREC_AMD_REHEARSAL_AR_GBS", "0"))
+    if ar_gbs > 0:
+        real_ar = dist.all_reduce
+        ar_stream = side_stream(dev)
+        cyc_us = _link_state["cycles"] / fwd_us
+
+        def all_reduce(tensor, op=dist.ReduceOp.SUM, group=None, async_op=False):
+            if not tensor.is_cuda:
+                return real_ar(tensor, op=op, group=group, async_op=async_op)
+            us = 20.0 + tensor.numel() * tensor.element_size() / (ar_gbs * 1e3)
+            ar_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(ar_stream):
+                torch.cuda._sleep(max(int(us * cyc_us), 1))
+                work = real_ar(tensor, op=op, group=group, async_op=async_op)
+            tensor.record_stream(ar_stream)
+            if not async_op:
+                torch.cuda.current_stream().wait_stream(ar_stream)
+            return work
+
+        dist.all_reduce = all_reduce
 
     dist.all_to_all_single = all_to_all_single

@@ -67,9 +67,21 @@ _DEFER_WGRAD = os.environ.get("TORCHREC_AMD_DEFER_WGRAD", "1") != "0"
 # this-many Linear layers are captured into a third graph that the explicit step replays AFTER it has started the NEXT step's
 # lookup + pooled all-to-all (the rest stays behind this step's gradient all-to-all).  The forward all-to-all then has the
 # same kind of cover the gradient all-to-all always had, instead of the bottom MLP's forward only.  0 = off.
-# (default 3 of the 5 head layers: with emulated links 2 / 3 / 4 measure 1.710 / 1.720 / 1.792 ms at the 8-GPU shape and
-# 3.179 / 3.105 / 3.146 at the 4-GPU one: profiles/r03_rehearsal_late_wgrads.txt)
-_WGRAD_LATE_LAYERS = int(os.environ.get("TORCHREC_AMD_WGRAD_LATE_LAYERS", "3"))
+# "auto" (default): 2 layers at per-rank batches of 16 384 .. 32 767 (N = 4 at the global batch of 65 536), none otherwise.
+# Why not everywhere: the late layers' gradients are all-reduced at the very end of the step, in front of the dense
+# optimizer and the next bottom MLP, and that all-reduce takes the same time at every batch size while the GEMMs that are
+# supposed to hide the all-to-all shrink with it.  With emulated link AND all-reduce times 0 / 2 / 3 late
+# layers measure 2.08 / 2.32 / 2.33 ms at 8192 per rank, 3.71 / 3.50 / 3.60 at 16 384; without the all-reduce time
+# 1.87 / 1.71 / 1.72 and 3.38 / 3.18 / 3.11.  A number forces it.
+_WGRAD_LATE_LAYERS = os.environ.get("TORCHREC_AMD_WGRAD_LATE_LAYERS", "auto")
+
+
+def _late_layers(batch: int, halves: bool) -> int:
+    if _WGRAD_LATE_LAYERS != "auto":
+        return int(_WGRAD_LATE_LAYERS)
+    return 2 if (not halves and 16384 <= batch < 32768) else 0
+
+
 # whole-batch explicit step with an exchange: unpack / pack captured into the head segment's graphs instead of two eager
 # launches (persistent receive / send buffers).  Opt-in: bit-identical, the two launch gaps (8 + 7 us) do disappear, and the
 # step gets no faster — 1.732 vs 1.695 ms at 8192 per rank, 2.849 vs 2.854 at 16 384 (the host, freed earlier, starts the
@@ -461,7 +473,7 @@ class DLRMTrain(nn.Module):
         if flat_grads and _DEFER_WGRAD and _EXPLICIT_STEP and getattr(ebc, "_exchange", False):
             # (weight, bias) of the over arch's first layers: the leading parameters of the head segment
             n_lin = sum(1 for q in g_head._params if q.dim() == 2)
-            late = 2 * min(_WGRAD_LATE_LAYERS, max(n_lin - 1, 0))
+            late = 2 * min(_late_layers(B, halves), max(n_lin - 1, 0))
             if late and not all(g_head._params[j].dim() == (2 if j % 2 == 0 else 1) for j in range(late)):
                 late = 0  # not a plain (weight, bias) sequence: keep everything in the second graph
         # the embedding collection writes its pooled output straight into the head segment's static input
