@@ -145,6 +145,11 @@ def test_late_weight_gradients_behind_the_prefetched_lookup_change_no_bit():
     assert late["checks"]["loss_first"] == plain["checks"]["loss_first"]
     assert late["checks"]["loss_last"] == plain["checks"]["loss_last"]
     assert late["checks"]["param_checksum"] == plain["checks"]["param_checksum"]
+    # the same again with the split-off weight gradients FIRST in the backward window, their all-reduce behind them (opt-in)
+    early = _run(dict(env, TORCHREC_AMD_WGRAD_SPLIT_MODE="early", TORCHREC_AMD_FORCE_DENSE_REDUCE="1"), "--global-batch", "4096")
+    assert early["prefetched_lookups"] == 0
+    assert early["checks"]["loss_last"] == plain["checks"]["loss_last"]
+    assert early["checks"]["param_checksum"] == plain["checks"]["param_checksum"]
     # the same again with the dense gradient all-reduces of an N > 1 run ISSUED (head slice without the late part, the rest,
     # the late part; on their own RCCL communicator) although one rank needs none: the call sequence of a real rank
     forced = _run(dict(env, TORCHREC_AMD_FORCE_DENSE_REDUCE="1"), "--global-batch", "4096")

@@ -82,6 +82,19 @@ def _late_layers(batch: int, halves: bool) -> int:
     return 2 if (not halves and 16384 <= batch < 32768) else 0
 
 
+# Where the split-off graph of those layers runs: "late" (default) = behind the next step's prefetched lookup, as above;
+# "early" = FIRST in the backward window, its slice of the flat gradient all-reduced right behind it, so that the all-reduce
+# of the head's largest layers overlaps the other weight gradients, the bottom MLP's backward and the embedding update.
+# Opt-in: bit-identical, and with emulated link + all-reduce times no faster than no split at all (2.095 vs 2.074 ms at 8192
+# per rank, 3.72 vs 3.65 at 16 384): what stays exposed is the LAST all-reduce (bottom MLP + replicated tables), whichever
+# way the head's is cut.
+_WGRAD_SPLIT_MODE = os.environ.get("TORCHREC_AMD_WGRAD_SPLIT_MODE", "late")
+
+
+def _split_mode(batch: int) -> str:
+    return _WGRAD_SPLIT_MODE
+
+
 # whole-batch explicit step with an exchange: unpack / pack captured into the head segment's graphs instead of two eager
 # launches (persistent receive / send buffers).  Opt-in: bit-identical, the two launch gaps (8 + 7 us) do disappear, and the
 # step gets no faster — 1.732 vs 1.695 ms at 8192 per rank, 2.849 vs 2.854 at 16 384 (the host, freed earlier, starts the
@@ -514,6 +527,7 @@ class DLRMTrain(nn.Module):
             object.__setattr__(self, "_graph_exchange", hooks is not None)
             if flat_grads:
                 state["n_late"] = sum(q.numel() for q in g_head._params[:late]) if g_head.bwd_graph3 is not None else 0
+                state["split_mode"] = _split_mode(B)
             # the head's gradient w.r.t. the bottom-MLP output doubles as the bottom segment's grad_output buffer
             g_dense.capture_backward([g_head.static_grad_inputs[0]], param_grad_sinks=dense_sinks, sink_scale=scale,
                                      defer_wgrad=flat_grads and _DEFER_WGRAD)
@@ -622,7 +636,9 @@ class DLRMTrain(nn.Module):
         """True when the captured head segment keeps part of its weight gradients for the window behind the next step's
         prefetched lookup (capture_hip_graphs, TORCHREC_AMD_WGRAD_LATE_LAYERS): the pipeline then prefetches by default."""
         g = getattr(self, "_graphs", None)
-        return bool(g is not None and getattr(g[2], "bwd_graph3", None) is not None)
+        st = getattr(self, "_flat_dense", None)
+        return bool(g is not None and getattr(g[2], "bwd_graph3", None) is not None
+                    and (st is None or st.get("split_mode", "late") == "late"))
 
     def take_backward_done(self) -> bool:
         """True (once) when the latest forward() already ran the backward: the caller must not call loss.backward()."""
@@ -691,6 +707,14 @@ class DLRMTrain(nn.Module):
                     object.__setattr__(self, "_loss_grad_ready", True)
                 g_head.bwd_graph.replay()  # ends with the gradient of the pooled embeddings
                 step.start_backward(g_head.static_grad_inputs[1].view(B, -1))  # pack + gradient all-to-all (+ replicated tables)
+                st = getattr(self, "_flat_dense", None)
+                early = (getattr(g_head, "bwd_graph3", None) is not None and st is not None
+                         and st.get("split_mode") == "early")
+                if early:
+                    # the split-off weight gradients (the head's largest layers) first, their all-reduce right behind them:
+                    # it overlaps everything below
+                    g_head.bwd_graph3.replay()
+                    st["reduce_late"]()
                 if getattr(g_head, "bwd_graph2", None) is not None:
                     g_head.bwd_graph2.replay()  # the head's weight gradients, while the all-to-all is in flight
                 if g_head.after_backward is not None:
@@ -707,7 +731,7 @@ class DLRMTrain(nn.Module):
             prefetch = getattr(self, "_prefetch", None)
             if prefetch is not None:
                 object.__setattr__(self, "_prefetched", prefetch())  # (kjt, ExplicitLookupStep) of the NEXT batch, or None
-            if getattr(g_head, "bwd_graph3", None) is not None:
+            if getattr(g_head, "bwd_graph3", None) is not None and not early:
                 # the late part of the head's weight gradients: behind the NEXT step's lookup + pooled all-to-all when the
                 # owner prefetches (its cover on the links), right here otherwise
                 g_head.bwd_graph3.replay()
