@@ -469,6 +469,9 @@ def _e2e_worker(rank, W, port, ret, hip_graphs=False):
         from torchrec_amd.distributed.types import ShardingEnv
 
         halves = hip_graphs == "flat-halves"  # the exchange in two half-batches (capture_hip_graphs(half_batches=True))
+        if hip_graphs == "flat-early":  # every piece of the flat gradient all-reduced as soon as it exists (split mode "early")
+            os.environ["TORCHREC_AMD_WGRAD_SPLIT_MODE"] = "early"
+            hip_graphs = "flat"
         if halves:
             hip_graphs = "flat"
         keys, model, opt = _e2e_model(ShardingEnv.from_process_group(dist.group.WORLD), dev, dp_max_rows=10,
@@ -492,7 +495,7 @@ def _e2e_worker(rank, W, port, ret, hip_graphs=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("hip_graphs", [False, True, "flat", "flat-halves"])
+@pytest.mark.parametrize("hip_graphs", [False, True, "flat", "flat-halves", "flat-early"])
 def test_dlrm_train_world2_on_one_gpu_matches_world1(hip_graphs):
     """hip_graphs=True: the dense segments replay from HIP graphs under DistributedDataParallel — captured
     BEFORE the DDP wrap (capturing a backward graph over DDP-managed parameters crashes in

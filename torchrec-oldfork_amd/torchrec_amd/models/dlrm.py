@@ -83,11 +83,10 @@ def _late_layers(batch: int, halves: bool) -> int:
 
 
 # Where the split-off graph of those layers runs: "late" (default) = behind the next step's prefetched lookup, as above;
-# "early" = FIRST in the backward window, its slice of the flat gradient all-reduced right behind it, so that the all-reduce
-# of the head's largest layers overlaps the other weight gradients, the bottom MLP's backward and the embedding update.
-# Opt-in: bit-identical, and with emulated link + all-reduce times no faster than no split at all (2.095 vs 2.074 ms at 8192
-# per rank, 3.72 vs 3.65 at 16 384): what stays exposed is the LAST all-reduce (bottom MLP + replicated tables), whichever
-# way the head's is cut.
+# "early" = FIRST in the backward window, and every piece of the flat gradient is all-reduced as soon as it exists, the
+# largest first (replicated tables, the split-off head layers, the other head layers; the bottom MLP's small slice last).
+# Opt-in: bit-identical, four collectives per step instead of two, and with emulated link + all-reduce times within noise of
+# no split at all (2.02 vs 2.05 ms at 8192 per rank; 3.71 vs 3.49 for "late" at 16 384).
 _WGRAD_SPLIT_MODE = os.environ.get("TORCHREC_AMD_WGRAD_SPLIT_MODE", "late")
 
 
@@ -456,7 +455,8 @@ class DLRMTrain(nn.Module):
             extra_views = views(extras, n_head + n_dense)
             state = {"flat": flat, "flat_param": flat_param, "params": list(g_head._params) + list(g_dense._params) + extras,
                      "views": head_sinks + dense_sinks + extra_views, "extras": list(zip(extras, extra_views)),
-                     "n_head": n_head, "works": [], "pg": dense_pg, "world": world, "scale": scale, "reduce": reduce}
+                     "n_head": n_head, "n_dense": n_dense, "works": [], "pg": dense_pg, "world": world, "scale": scale,
+                     "reduce": reduce}
 
             def reduce_head():  # the head's backward runs first: its slice overlaps the rest of backward
                 state["fired"] += 1
@@ -566,6 +566,20 @@ class DLRMTrain(nn.Module):
             return
         import torch.distributed as dist
 
+        self._fold_extras(st)
+        if st["reduce"]:
+            if st.get("pieces_done"):  # "early" split mode: head and replicated tables are on their way, the bottom MLP is left
+                lo, hi = st["n_head"], st["n_head"] + st["n_dense"]
+            else:
+                lo, hi = (st["n_late"] if st.get("n_late", 0) else st["n_head"]), st["flat"].numel()  # (see reduce_head)
+            st["works"].append(dist.all_reduce(st["flat"][lo:hi], group=st["pg"], async_op=True))
+        st["rest_started"] = True
+        st["pieces_done"] = False
+
+    @staticmethod
+    def _fold_extras(st) -> None:
+        if st.get("extras_folded"):
+            return
         for q, v in st["extras"]:
             if q.grad is None:
                 v.zero_()
@@ -573,10 +587,7 @@ class DLRMTrain(nn.Module):
                 torch.mul(q.grad, st["scale"], out=v)
             elif st["scale"] != 1.0:
                 v.mul_(st["scale"])  # autograd accumulated in place (zero_grad(set_to_none=False))
-        if st["reduce"]:
-            lo = st["n_late"] if st.get("n_late", 0) else st["n_head"]  # (see reduce_head)
-            st["works"].append(dist.all_reduce(st["flat"][lo:], group=st["pg"], async_op=True))
-        st["rest_started"] = True
+        st["extras_folded"] = True
 
     def finish_dense_grads(self) -> None:
         """After backward: folds the autograd gradients of the non-graphed dense parameters into the flat
@@ -611,6 +622,7 @@ class DLRMTrain(nn.Module):
         else:
             self._start_rest_reduce(st)
         st["rest_started"] = False
+        st["extras_folded"] = False
         for w in st["works"]:
             w.wait()
         st["works"].clear()
@@ -711,13 +723,24 @@ class DLRMTrain(nn.Module):
                 early = (getattr(g_head, "bwd_graph3", None) is not None and st is not None
                          and st.get("split_mode") == "early")
                 if early:
-                    # the split-off weight gradients (the head's largest layers) first, their all-reduce right behind them:
-                    # it overlaps everything below
+                    # every piece of the flat gradient is all-reduced as soon as it exists, the largest first: the replicated
+                    # tables' (written by start_backward above), the head's largest layers', the head's other layers' — and
+                    # the bottom MLP's small slice last (_start_rest_reduce), behind its backward graphs
+                    import torch.distributed as dist
+
+                    self._fold_extras(st)
+                    if st["reduce"]:
+                        st["works"].append(dist.all_reduce(st["flat"][st["n_head"] + st["n_dense"]:], group=st["pg"], async_op=True))
                     g_head.bwd_graph3.replay()
                     st["reduce_late"]()
                 if getattr(g_head, "bwd_graph2", None) is not None:
                     g_head.bwd_graph2.replay()  # the head's weight gradients, while the all-to-all is in flight
-                if g_head.after_backward is not None:
+                if early:
+                    st["fired"] += 1
+                    if st["reduce"]:
+                        st["works"].append(dist.all_reduce(st["flat"][st["n_late"]:st["n_head"]], group=st["pg"], async_op=True))
+                    st["pieces_done"] = True
+                elif g_head.after_backward is not None:
                     g_head.after_backward()  # all-reduce of the head's slice of the flat gradient
                 g_dense.bwd_graph.replay()  # its grad_output buffer IS the head's gradient w.r.t. the bottom-MLP output
                 if getattr(g_dense, "bwd_graph2", None) is not None:
