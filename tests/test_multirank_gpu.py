@@ -232,14 +232,17 @@ def test_row_wise_input_dist_modes_world2_on_one_gpu(fixed_len, weighted, n_rw, 
     _check_against_oracle(ret, W, fixed_len, weighted, n_rw, dp_max_rows, adagrad=adagrad, max_len=6)
 
 
-def _rccl_worker(rank, port, fixed_len, weighted, dp_max_rows, ret):
+def _rccl_worker(rank, port, fixed_len, weighted, dp_max_rows, ret, plain_group=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(0)
     from torchrec_amd.distributed.comm import init_rccl_process_group
 
-    init_rccl_process_group(torch.device("cuda", 0), rank=0, world_size=1)
+    if plain_group:  # what a launcher written for CUDA does (examples/dlrm/dlrm_main.py:469-478)
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    else:
+        init_rccl_process_group(torch.device("cuda", 0), rank=0, world_size=1)
     try:
         import torchrec_amd.distributed.embeddingbag as eb
         from torchrec_amd.distributed.types import ShardingEnv
@@ -248,6 +251,10 @@ def _rccl_worker(rank, port, fixed_len, weighted, dp_max_rows, ret):
         per_rank, init = _data(1, fixed_len, weighted)
         keys, plan, sebc = _build_sharded(1, ShardingEnv.from_process_group(dist.group.WORLD), weighted, 0, dp_max_rows)
         assert sebc._exchange
+        # the exchanges run on a high-priority collective stream either way: the environment's group if it has one, else a
+        # second communicator the sharded module made for itself (distributed/comm.py exchange_group)
+        assert (sebc._pg is dist.group.WORLD) == (not plain_group)
+        assert sebc._pg._get_backend(torch.device("cuda", 0)).options.is_high_priority_stream
         out, shards = _run_rank(sebc, keys, per_rank, init, 0, 1, fixed_len, weighted)
         ret[0] = (out, shards, {n: p.sharding_type for n, p in plan.items()})
     finally:
@@ -361,11 +368,13 @@ def test_row_wise_shards_report_exactly_the_truly_out_of_range_ids(offload):
         assert ret[f"errors{r}"] == expect, (r, ret[f"errors{r}"], expect)
 
 
-@pytest.mark.parametrize("fixed_len,weighted,dp_max_rows", [(1, False, 10), (0, True, 0)])
-def test_exchange_through_rccl_world1(fixed_len, weighted, dp_max_rows):
-    """The asynchronous id + pooled all-to-all and the exchange kernels over a real RCCL group."""
+@pytest.mark.parametrize("fixed_len,weighted,dp_max_rows,plain_group", [(1, False, 10, False), (0, True, 0, False),
+                                                                        (1, False, 10, True)])
+def test_exchange_through_rccl_world1(fixed_len, weighted, dp_max_rows, plain_group):
+    """The asynchronous id + pooled all-to-all and the exchange kernels over a real RCCL group; plain_group: the process
+    group as a CUDA launcher creates it — the sharded module then makes itself a communicator with a high-priority stream."""
     ret = ResultStore()
-    mp.spawn(_rccl_worker, args=(_free_port(), fixed_len, weighted, dp_max_rows, ret), nprocs=1, join=True)
+    mp.spawn(_rccl_worker, args=(_free_port(), fixed_len, weighted, dp_max_rows, ret, plain_group), nprocs=1, join=True)
     _check_against_oracle(ret, 1, fixed_len, weighted, 0, dp_max_rows)
 
 

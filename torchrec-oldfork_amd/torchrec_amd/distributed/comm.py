@@ -35,3 +35,28 @@ def new_rccl_group(process_group=None, high_priority: Optional[bool] = None):
     all-reduces there, clear of the pooled all-to-alls.  Collective: every rank of the default group must call it."""
     ranks = dist.get_process_group_ranks(process_group if process_group is not None else dist.group.WORLD)
     return dist.new_group(ranks=ranks, pg_options=rccl_options(high_priority))
+
+
+_exchange_groups = {}
+
+
+def exchange_group(process_group, device) -> Optional["dist.ProcessGroup"]:
+    """The group a sharded module's id / pooled exchanges should run on: `process_group` itself when it is not RCCL or its
+    collective stream is already high-priority (init_rccl_process_group), else a second communicator over the same ranks
+    whose stream is (new_rccl_group; one per process group, shared by every sharded module).  This is what lets a launcher
+    written for CUDA — `dist.init_process_group(backend="nccl")`, examples/dlrm/dlrm_main.py:469-478 — run unmodified without
+    the exchange landing on the compute stream's hardware queue.  Collective when it creates the group: sharded modules are
+    built by every rank.  TORCHREC_AMD_OWN_EXCHANGE_GROUP=0: always `process_group`."""
+    if process_group is None or os.environ.get("TORCHREC_AMD_OWN_EXCHANGE_GROUP", "1") != "1":
+        return process_group
+    try:
+        if dist.get_backend(process_group) != "nccl":
+            return process_group
+        if bool(process_group._get_backend(torch.device(device)).options.is_high_priority_stream):
+            return process_group
+    except Exception:  # cannot tell: leave the caller's group alone
+        return process_group
+    key = id(process_group)
+    if key not in _exchange_groups:
+        _exchange_groups[key] = new_rccl_group(process_group, high_priority=True)
+    return _exchange_groups[key]

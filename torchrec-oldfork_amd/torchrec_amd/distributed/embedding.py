@@ -101,6 +101,10 @@ class ShardedEmbeddingCollection(nn.Module):
         super().__init__()
         self._pg, self._W, self._me = env.process_group, env.world_size, env.rank
         self._device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if self._W > 1 and self._device.type == "cuda":
+            from .comm import exchange_group
+
+            self._pg = exchange_group(env.process_group, self._device)  # (see ShardedEmbeddingBagCollection)
         dims = {c.embedding_dim for c in tables}
         if len(dims) != 1:
             raise ValueError("All tables in a EmbeddingCollection are required to have same embedding dimension.")

@@ -441,11 +441,16 @@ class ShardedEmbeddingBagCollection(nn.Module):
         if rw_input_dist not in ("auto", "windows", "bucketize"):
             raise ValueError("rw_input_dist must be auto, windows or bucketize")
         self._rw_input_dist = rw_input_dist
-        self._pg = env.process_group
         W, me = env.world_size, env.rank
         self._world_size, self._rank = W, me
-        self._exchange = W > 1 or (FORCE_EXCHANGE and self._pg is not None)
+        self._exchange = W > 1 or (FORCE_EXCHANGE and env.process_group is not None)
         self._device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        # the exchanges' group: the environment's, or — for an RCCL group whose collective stream is not high-priority, i.e. a
+        # launcher written for CUDA — a second communicator whose stream is, clear of the compute stream's hardware queue
+        from .comm import exchange_group
+
+        self._pg = exchange_group(env.process_group, self._device) if (self._exchange and self._device.type == "cuda") \
+            else env.process_group
         self._is_weighted = module.is_weighted
         cfgs = module.embedding_bag_configs
         self._embedding_bag_configs = cfgs
