@@ -57,6 +57,12 @@ def exchange_group(process_group, device) -> Optional["dist.ProcessGroup"]:
     except Exception:  # cannot tell: leave the caller's group alone
         return process_group
     key = id(process_group)
-    if key not in _exchange_groups:
-        _exchange_groups[key] = new_rccl_group(process_group, high_priority=True)
-    return _exchange_groups[key]
+    hit = _exchange_groups.get(key)
+    if hit is not None:
+        parent, own = hit
+        alive = getattr(dist.distributed_c10d, "_world", None)
+        if parent is process_group and (alive is None or own in alive.pg_map):  # (not a new group at a recycled address,
+            return own                                                         #  not one destroy_process_group() took down)
+    own = new_rccl_group(process_group, high_priority=True)
+    _exchange_groups[key] = (process_group, own)
+    return own

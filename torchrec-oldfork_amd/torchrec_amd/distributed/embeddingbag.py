@@ -209,9 +209,12 @@ class _ExchangeState:
         self._half_send_keepalive: List[torch.Tensor] = []
         self.static = None
 
-    def start_forward(self, emb: torch.Tensor) -> None:
+    def start_forward(self, emb: torch.Tensor, allow_static: bool = False) -> None:
         o, lay = self.o, self.lay
-        static = o._static_exchange if (o._static_exchange is not None and o._static_exchange["B"] == self.B) else None
+        # (the persistent buffers serve the explicit train step only: an eval forward between two steps must not receive
+        # into the buffer that holds the next step's prefetched embeddings)
+        static = o._static_exchange if (allow_static and o._static_exchange is not None
+                                        and o._static_exchange["B"] == self.B) else None
         self.static = static  # persistent receive / send buffers: the owner's graphs unpack / pack (set_graph_exchange)
         self.recv_fwd = (static["recv_fwd"] if static is not None
                          else torch.empty(lay["recv_numel"], dtype=torch.float32, device=emb.device))
@@ -1164,7 +1167,7 @@ class ExplicitLookupStep:
             if self.halves:
                 self.state.start_forward_halves(emb)
             else:
-                self.state.start_forward(emb)
+                self.state.start_forward(emb, allow_static=True)
             # the replicated tables' lookup does not depend on the exchange: it fills its columns of the destination
             # while the all-to-all (on its own hardware queue) is in flight, instead of after the wait
             # (NOT when this step is prefetched at the end of the previous one: the replicated tables are dense parameters,
