@@ -121,3 +121,26 @@ def test_rccl_options_put_the_collective_stream_on_its_own_priority(monkeypatch)
     assert rccl_options(False).is_high_priority_stream is False
     monkeypatch.setenv("TORCHREC_AMD_RCCL_HIGH_PRIORITY", "0")
     assert rccl_options().is_high_priority_stream is False
+
+
+def test_exchange_group_leaves_non_rccl_groups_alone():
+    """torchrec_amd/distributed/comm.py exchange_group: only an RCCL group with a normal-priority collective stream gets a
+    second communicator; gloo groups (CPU tests, the one-GPU rehearsal) and None are returned as they are."""
+    import os
+    import socket
+
+    import torch.distributed as dist
+
+    from torchrec_amd.distributed.comm import exchange_group
+
+    assert exchange_group(None, "cpu") is None
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        assert exchange_group(dist.group.WORLD, "cpu") is dist.group.WORLD
+    finally:
+        dist.destroy_process_group()
