@@ -90,10 +90,6 @@ def _late_layers(batch: int, halves: bool) -> int:
 _WGRAD_SPLIT_MODE = os.environ.get("TORCHREC_AMD_WGRAD_SPLIT_MODE", "late")
 
 
-def _split_mode(batch: int) -> str:
-    return _WGRAD_SPLIT_MODE
-
-
 # whole-batch explicit step with an exchange: unpack / pack captured into the head segment's graphs instead of two eager
 # launches (persistent receive / send buffers).  Opt-in: bit-identical, the two launch gaps (8 + 7 us) do disappear, and the
 # step gets no faster — 1.732 vs 1.695 ms at 8192 per rank, 2.849 vs 2.854 at 16 384 (the host, freed earlier, starts the
@@ -527,7 +523,7 @@ class DLRMTrain(nn.Module):
             object.__setattr__(self, "_graph_exchange", hooks is not None)
             if flat_grads:
                 state["n_late"] = sum(q.numel() for q in g_head._params[:late]) if g_head.bwd_graph3 is not None else 0
-                state["split_mode"] = _split_mode(B)
+                state["split_mode"] = _WGRAD_SPLIT_MODE
             # the head's gradient w.r.t. the bottom-MLP output doubles as the bottom segment's grad_output buffer
             g_dense.capture_backward([g_head.static_grad_inputs[0]], param_grad_sinks=dense_sinks, sink_scale=scale,
                                      defer_wgrad=flat_grads and _DEFER_WGRAD)
