@@ -191,3 +191,55 @@ def test_copy_rows_rejects_unaligned_rows():
     src = torch.zeros((4, 3), dtype=torch.int32, device="cuda")
     with pytest.raises(RuntimeError, match="16"):
         torch.ops.tbe_hip.copy_rows(src, torch.tensor([1, 0], dtype=torch.int32, device="cuda"))
+
+
+@pytest.mark.parametrize("vec", [True, False])
+@pytest.mark.parametrize("W,B", [(4, 37), (2, 64), (8, 5)])
+def test_pooled_exchange_kernels_bit_exact_vs_oracle(W, B, vec):
+    """csrc/pooled_exchange.hip against oracle/tbe_oracle.c, bit for bit: table-wise features (copy from / to the owner's
+    slab), row-wise features (sum of W partials in rank order / broadcast) and replicated features (columns the exchange
+    must leave alone) mixed in one matrix, odd batch sizes, the 1/W scale of the gradient; 16-B vector and scalar forms.
+    (A row-major rewrite of the kernel — per-thread column slots resolved once, no division / search per element — passed
+    this test and was no faster: the kernel already moves 5.5 TB/s at the 8-rank shape, tools/xbench.py.  Not kept.)"""
+    import torchrec_amd.distributed._device_ops  # noqa: F401  (registers torch.ops.tbe_hip.*)
+
+    rng = np.random.default_rng(W * 100 + B)
+    dims = [128, 64, 128, 32, 128, 64, 128, 128, 16, 128]
+    kinds = [0, -1, -2, 1 % W, -2, -1, (W - 1), 0, -2, 1 % W]  # owner rank, -1 row-wise, -2 replicated
+    out_col = np.concatenate([[0], np.cumsum(dims)]).astype(np.int32)
+    D_total = int(out_col[-1])
+    # slab of rank r = [every row-wise feature | r's table-wise features], in feature order: a row-wise feature sits at the
+    # same column of every slab
+    slab_cols = np.zeros(len(dims), dtype=np.int32)
+    rw_width = 0
+    for f, k in enumerate(kinds):
+        if k == -1:
+            slab_cols[f] = rw_width
+            rw_width += dims[f]
+    widths = [rw_width] * W
+    for f, k in enumerate(kinds):
+        if k >= 0:
+            slab_cols[f] = widths[k]
+            widths[k] += dims[f]
+    slab_stride = np.array(widths, dtype=np.int32)
+    slab_offset = np.concatenate([[0], np.cumsum([B * w for w in widths])])[:-1].astype(np.int64)
+    numel = int(sum(B * w for w in widths))
+    dev = "cuda"
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    args = (t(out_col), t(np.array(kinds, dtype=np.int32)), t(slab_cols), t(slab_offset), t(slab_stride))
+    recv = rng.standard_normal(numel).astype(np.float32)
+    want = oracle.pooled_exchange(recv, out_col, np.array(kinds, dtype=np.int32), slab_cols, slab_offset, slab_stride, B, False, 1.0)
+    got = torch.full((B, D_total), 7.5, device=dev)
+    torch.ops.tbe_hip.pooled_exchange_unpack_into(t(recv), *args, B, D_total, vec, 1.0, got)
+    got = got.cpu().numpy()
+    for f, k in enumerate(kinds):
+        cols = slice(int(out_col[f]), int(out_col[f + 1]))
+        if k == -2:
+            assert (got[:, cols] == 7.5).all()  # replicated features: untouched
+        else:
+            np.testing.assert_array_equal(got[:, cols], want[:, cols])
+    grad = rng.standard_normal((B, D_total)).astype(np.float32)
+    want_p = oracle.pooled_exchange(grad, out_col, np.array(kinds, dtype=np.int32), slab_cols, slab_offset, slab_stride, B, True,
+                                    1.0 / W, numel)
+    got_p = torch.ops.tbe_hip.pooled_exchange_pack(t(grad), *args, numel, vec, 1.0 / W).cpu().numpy()
+    np.testing.assert_array_equal(got_p, want_p)
