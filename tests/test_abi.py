@@ -144,3 +144,16 @@ def test_exchange_group_leaves_non_rccl_groups_alone():
         assert exchange_group(dist.group.WORLD, "cpu") is dist.group.WORLD
     finally:
         dist.destroy_process_group()
+
+
+def test_explicit_step_policies():
+    """models/dlrm.py defaults: late weight-gradient layers only at per-rank batches of 16 384 .. 32 767 (and never in
+    half-batch mode), half-batches from 32 768 — the crossovers measured with emulated link / all-reduce times
+    (DESIGN.md §4)."""
+    import torchrec_amd.models.dlrm as dlrm
+
+    if dlrm._WGRAD_LATE_LAYERS == "auto":
+        assert [dlrm._late_layers(b, False) for b in (4096, 8192, 16384, 32767, 32768, 65536)] == [0, 0, 2, 2, 0, 0]
+        assert dlrm._late_layers(16384, True) == 0 and dlrm._late_layers(32768, True) == 0
+    assert dlrm._HALF_BATCH_MIN == 32768 or "TORCHREC_AMD_HALF_BATCH_MIN" in __import__("os").environ
+    assert dlrm._WGRAD_SPLIT_MODE in ("late", "early") and dlrm._GRAPH_EXCHANGE in (False, True)
